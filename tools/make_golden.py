@@ -1,0 +1,151 @@
+"""Generate tests/golden/*.npz from the IMPORTED REFERENCE (build container only).
+
+    python tools/make_golden.py            # writes tests/golden/
+
+The reference (read-only at /root/reference) is imported with stand-ins for its non-hot-path
+dependencies (tools/ref_import.py), given this repo's deterministic synthetic weights through
+`load_state_dict`, and run on CPU in float32 and float64.  Only DATA is stored: input recipes
+(seeds), and for every tap a strided sample plus sum / sum-of-squares.  No reference source is
+copied.  The fixtures pin `oracle/` (tests/test_oracle_golden.py) and, on the GPU box, the HIP
+path (tests/test_gpu_*.py) without /root/reference being present.
+"""
+import os
+import random
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+from demucs_amd.weights import HTDemucsConfig, synthetic_state_dict       # noqa: E402
+from demucs_amd.synth import synth_mix                                    # noqa: E402
+from ref_import import import_reference, build_reference_htdemucs         # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+SL = 343980
+
+
+def sample(t: torch.Tensor, n_max: int = 2048):
+    """strided sample + moments of a tensor (float64 moments)."""
+    flat = t.detach().reshape(-1)
+    stride = max(1, flat.numel() // n_max)
+    d = flat.double()
+    return dict(shape=np.array(t.shape), stride=np.array(stride), sample=flat[::stride].cpu().numpy().copy(),
+                sum=np.array(d.sum().item()), sumsq=np.array((d * d).sum().item()))
+
+
+def pack(prefix: str, s: dict, store: dict):
+    for k, v in s.items():
+        store[f"{prefix}/{k}"] = v
+
+
+def segment_fixture(name: str, cfg: HTDemucsConfig, wseed: int, mix: np.ndarray):
+    """One-segment forward of the reference with per-stage taps (forward hooks)."""
+    store = {"meta/wseed": np.array(wseed), "meta/n_sources": np.array(len(cfg.sources))}
+    sd = synthetic_state_dict(cfg, wseed)
+    for tag, dtype in (("f32", torch.float32), ("f64", torch.float64)):
+        model = build_reference_htdemucs(cfg, sd, dtype)
+        taps = {}
+        hooks = []
+
+        def mk(nm, pick=None):
+            def hook(mod, inp, out):
+                taps[nm] = out if pick is None else out[pick]
+            return hook
+        for i in range(4):
+            hooks.append(model.encoder[i].register_forward_hook(mk(f"enc{i}" if i else "enc0_preemb")))
+            hooks.append(model.tencoder[i].register_forward_hook(mk(f"tenc{i}")))
+            hooks.append(model.decoder[i].register_forward_hook(mk(f"dec{i}", 0)))
+            hooks.append(model.tdecoder[i].register_forward_hook(mk(f"tdec{i}", 0)))
+        for idx in range(5):
+            hooks.append(model.crosstransformer.layers[idx].register_forward_hook(mk(f"tr{idx}_f")))
+            hooks.append(model.crosstransformer.layers_t[idx].register_forward_hook(mk(f"tr{idx}_t")))
+        hooks.append(model.channel_downsampler.register_forward_hook(mk("bott_f")))
+        hooks.append(model.channel_downsampler_t.register_forward_hook(mk("bott_t")))
+        x = torch.from_numpy(mix).to(dtype)[None]
+        t0 = time.time()
+        with torch.no_grad():
+            out = model(x)
+            xp = torch.nn.functional.pad(x, (0, SL - x.shape[-1]))       # htdemucs.py:535-537
+            z = model._magnitude(model._spec(xp))
+        print(f"  {name} {tag}: {time.time() - t0:.1f}s  out rms {out.pow(2).mean().sqrt():.4f}")
+        for h in hooks:
+            h.remove()
+        taps["stft"] = z
+        # transformer layer taps are (B, tokens, C) in the reference; store channel-first
+        for k in list(taps):
+            if k.startswith("tr"):
+                taps[k] = taps[k].transpose(1, 2)
+        taps["bott_f"] = taps["bott_f"].reshape(1, 384, 8, -1)
+        taps["out"] = out
+        for k, v in taps.items():
+            pack(f"{tag}/{k}", sample(v, 16384 if k == "out" else 2048), store)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **store)
+
+
+def apply_fixture(name: str, cfg: HTDemucsConfig, wseeds, bag_weights, mix: np.ndarray, rseed=None, **kw):
+    """Track-level `apply_model` of the reference (float32 model; float64 model for truth)."""
+    ref_apply, _ = import_reference()
+    store = {"meta/wseeds": np.array(wseeds), "meta/length": np.array(mix.shape[-1])}
+    for k, v in kw.items():
+        store[f"meta/kw_{k}"] = np.array(v)
+    if rseed is not None:
+        store["meta/rseed"] = np.array(rseed)
+    if bag_weights is not None:
+        store["meta/bag_weights"] = np.array(bag_weights)
+    for tag, dtype in (("f32", torch.float32), ("f64", torch.float64)):
+        models = [build_reference_htdemucs(cfg, synthetic_state_dict(cfg, s), dtype) for s in wseeds]
+        model = models[0] if bag_weights is None else ref_apply.BagOfModels(models, bag_weights)
+        events = []
+        if rseed is not None:
+            random.seed(rseed)
+        x = torch.from_numpy(mix).to(dtype)[None]
+        x0 = x.clone()
+        t0 = time.time()
+        out = ref_apply.apply_model(model, x, callback=lambda d: events.append(dict(d)), **kw)
+        assert torch.equal(x, x0), "apply_model must not mutate mix"
+        print(f"  {name} {tag}: {time.time() - t0:.1f}s  {len(events)} events, out rms {out.pow(2).mean().sqrt():.4f}")
+        pack(f"{tag}/out", sample(out, 16384), store)
+        if tag == "f32":
+            keys = ["model_idx_in_bag", "shift_idx", "segment_offset", "models", "state"]
+            store["events"] = np.array([[str(e[k]) for k in keys] for e in events])
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **store)
+
+
+def main():
+    global segment_fixture, apply_fixture
+    only = set(sys.argv[1:])
+    if only:                                   # regenerate just the named fixtures
+        seg_all, app_all = segment_fixture, apply_fixture
+        segment_fixture = lambda n, *a, **k: seg_all(n, *a, **k) if n in only else None    # noqa: E731
+        apply_fixture = lambda n, *a, **k: app_all(n, *a, **k) if n in only else None      # noqa: E731
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(0)
+    cfg4 = HTDemucsConfig()
+    cfg6 = HTDemucsConfig(sources=["drums", "bass", "other", "vocals", "guitar", "piano"])
+    print("segment fixtures")
+    segment_fixture("seg_noise_w0", cfg4, 0, synth_mix(123, SL, "noise"))
+    segment_fixture("seg_tones_w1", cfg4, 1, synth_mix(7, SL, "tones"))
+    segment_fixture("seg_short_w0", cfg4, 0, synth_mix(5, 100001, "tones"))      # right zero-pad path
+    segment_fixture("seg6_noise_w2", cfg6, 2, synth_mix(11, SL, "noise"))
+    print("apply fixtures")
+    # BASELINE config 1: one 7.8 s segment, shifts=0 -> 2 forwards (offsets 0 and 257985)
+    apply_fixture("apply_one_segment", cfg4, [0], None, synth_mix(1, SL, "noise"), shifts=0, split=True, overlap=0.25)
+    apply_fixture("apply_2p3_segments", cfg4, [0], None, synth_mix(2, int(2.3 * SL), "tones"),
+                  shifts=0, split=True, overlap=0.25)
+    apply_fixture("apply_sl_plus_1", cfg4, [1], None, synth_mix(3, SL + 1, "noise"), shifts=0, split=True, overlap=0.25)
+    apply_fixture("apply_shifts2", cfg4, [0], None, synth_mix(4, 300000, "tones"), rseed=0,
+                  shifts=2, split=True, overlap=0.25)
+    apply_fixture("apply_bag2_shift1", cfg4, [10, 11], [[1., 0., 0.5, 0.25], [0., 1., 0.5, 0.75]],
+                  synth_mix(5, 400000, "noise"), rseed=3, shifts=1, split=True, overlap=0.25)
+    apply_fixture("apply_nosplit_short", cfg4, [0], None, synth_mix(6, 200000, "tones"), shifts=0, split=False)
+    apply_fixture("apply_overlap10_tp2", cfg4, [1], None, synth_mix(8, int(1.5 * SL), "noise"),
+                  shifts=0, split=True, overlap=0.1, transition_power=2.0)
+
+
+if __name__ == "__main__":
+    main()
