@@ -1,0 +1,104 @@
+"""ctypes binding of libdemucs_amd.so (C ABI declared in include/demucs_amd.h).
+
+There is NO fallback: if the shared library is missing or fails to load, every entry point
+raises.  The product never routes through PyTorch eager ops or the CPU oracle.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdemucs_amd.so")
+
+MI_OK = 0
+
+
+class MiTensorDesc(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("data", C.c_void_p), ("numel", C.c_int64)]
+
+
+class MiConfig(C.Structure):
+    _fields_ = [("n_sources", C.c_int32), ("segment_length", C.c_int32), ("max_batch", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
+class MiConvDesc(C.Structure):
+    """mi_conv_desc of demucs_amd/csrc/gemm_conv.h (field order must match)."""
+    _fields_ = [
+        ("wt", C.c_void_p), ("M", C.c_int32), ("Mpad", C.c_int32), ("K", C.c_int32), ("Kpad", C.c_int32),
+        ("ktab", C.c_void_p),
+        ("x", C.c_void_p), ("x_bstride", C.c_int64),
+        ("B", C.c_int32), ("D1", C.c_int32), ("D2", C.c_int32), ("O1", C.c_int32), ("O2", C.c_int32),
+        ("S1", C.c_int32), ("S2", C.c_int32),
+        ("pro", C.c_int32), ("pro_stats", C.c_void_p), ("pro_w", C.c_void_p), ("pro_b", C.c_void_p),
+        ("row_mode", C.c_int32),
+        ("epi", C.c_int32), ("flags", C.c_int32),
+        ("bias", C.c_void_p), ("scale", C.c_void_p), ("res", C.c_void_p), ("emb", C.c_void_p),
+        ("y", C.c_void_p), ("y_bstride", C.c_int64), ("y_cstride", C.c_int64),
+        ("stats", C.c_void_p), ("gn_stats", C.c_void_p), ("gn_w", C.c_void_p), ("gn_b", C.c_void_p),
+        ("out_len", C.c_int32), ("tile_m", C.c_int32),
+    ]
+
+
+# symbol -> (restype, argtypes); every symbol declared in include/demucs_amd.h
+SIGNATURES = {
+    "mi_model_create": (C.c_int, [C.POINTER(MiConfig), C.POINTER(MiTensorDesc), C.c_size_t, C.POINTER(C.c_void_p)]),
+    "mi_model_destroy": (None, [C.c_void_p]),
+    "mi_model_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "mi_model_tap": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.c_void_p]),
+    "mi_model_device_bytes": (C.c_int64, [C.c_void_p]),
+    "mi_segments_gather": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
+                                     C.c_void_p]),
+    "mi_ola_accumulate": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
+    "mi_ola_finish": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32,
+                                C.c_int32, C.c_void_p, C.c_void_p]),
+    "mi_stft_cac": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "mi_istft_cac": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "mi_conv_forward": (C.c_int, [C.POINTER(MiConvDesc), C.c_void_p]),
+    "mi_attention": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                               C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_void_p]),
+    "mi_layernorm_cf": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_void_p]),
+    "mi_last_error": (C.c_char_p, []),
+    "mi_version": (C.c_char_p, []),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+class EngineError(RuntimeError):
+    """A libdemucs_amd call returned a non-zero status (the reference convention for this path
+    is "exceptions propagate", demucs/apply.py:289-293)."""
+
+
+def load() -> C.CDLL:
+    """dlopen the engine (once).  Raises EngineError if it is absent: no fallback exists."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise EngineError(
+                    f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                    "(hipcc --offload-arch=gfx950).  demucs_amd has no CPU / eager fallback.")
+            lib = C.CDLL(LIB_PATH)
+            for name, (res, args) in SIGNATURES.items():
+                fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+                fn.restype = res
+                fn.argtypes = args
+            _lib = lib
+    return _lib
+
+
+def check(status: int, what: str) -> None:
+    if status != MI_OK:
+        msg = load().mi_last_error().decode(errors="replace")
+        raise EngineError(f"{what} failed ({status}): {msg}")
+
+
+def current_stream_ptr() -> int:
+    import torch
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,184 @@
+// extern "C" surface of libdemucs_amd.so (declared in include/demucs_amd.h).
+#include <new>
+
+#include "common.h"
+#include "gemm_conv.h"
+#include "kernels.h"
+#include "model.h"
+
+namespace mi {
+
+char *last_error_buf() {
+    static thread_local char buf[1024] = "";
+    return buf;
+}
+
+int set_error(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(last_error_buf(), 1024, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+// small cache of FFT tables for the handle-free kernel-level entry points
+struct Tables {
+    FftTables t{};
+    bool ready = false;
+};
+static int get_tables(FftTables *out) {
+    static Tables tb;
+    if (!tb.ready) {
+        std::vector<float> win(4096), env(1024);
+        std::vector<float2> tw(2048);
+        for (int i = 0; i < 4096; ++i) win[i] = 0.5f - 0.5f * cosf((float)i * (float)(2.0 * M_PI / 4096.0));
+        for (int i = 0; i < 2048; ++i) { const double a = -2.0 * M_PI * i / 4096.0; tw[i] = make_float2((float)cos(a), (float)sin(a)); }
+        for (int r = 0; r < 1024; ++r) { float e = 0.f; for (int j = 3; j >= 0; --j) e += win[r + 1024 * j] * win[r + 1024 * j]; env[r] = e; }
+        float *dw, *de; float2 *dt;
+        MI_HIP(hipMalloc((void **)&dw, 4096 * 4)); MI_HIP(hipMalloc((void **)&dt, 2048 * 8)); MI_HIP(hipMalloc((void **)&de, 1024 * 4));
+        MI_HIP(hipMemcpy(dw, win.data(), 4096 * 4, hipMemcpyHostToDevice));
+        MI_HIP(hipMemcpy(dt, tw.data(), 2048 * 8, hipMemcpyHostToDevice));
+        MI_HIP(hipMemcpy(de, env.data(), 1024 * 4, hipMemcpyHostToDevice));
+        tb.t = FftTables{dw, dt, de};
+        tb.ready = true;
+    }
+    *out = tb.t;
+    return MI_OK;
+}
+
+}  // namespace mi
+
+using namespace mi;
+
+extern "C" {
+
+const char *mi_last_error(void) { return last_error_buf(); }
+const char *mi_version(void) { return "demucs_amd 0.1 gfx950"; }
+
+int mi_model_create(const mi_config *cfg, const mi_tensor_desc *weights, size_t n_weights, void **handle) {
+    if (!cfg || !weights || !handle) return set_error(MI_EINVAL, "mi_model_create: null argument");
+    *handle = nullptr;
+    Model *m = new (std::nothrow) Model();
+    if (!m) return set_error(MI_ENOMEM, "mi_model_create: host allocation failed");
+    const int r = m->init(*cfg, weights, n_weights);
+    if (r != MI_OK) { delete m; return r; }
+    *handle = m;
+    return MI_OK;
+}
+
+void mi_model_destroy(void *handle) {
+    if (!handle) return;
+    (void)hipDeviceSynchronize();
+    delete (Model *)handle;
+}
+
+int mi_model_forward(void *handle, const float *mix_dev, float *out_dev, int32_t B, void *stream) {
+    if (!handle) return set_error(MI_EINVAL, "mi_model_forward: null handle");
+    return ((Model *)handle)->forward(mix_dev, out_dev, B, (hipStream_t)stream);
+}
+
+int mi_model_tap(void *handle, const char *name, float *dst_dev, int32_t B, int64_t *numel_per_item, void *stream) {
+    if (!handle || !name || !numel_per_item) return set_error(MI_EINVAL, "mi_model_tap: null argument");
+    const float *src = nullptr;
+    const float **ptr_dev = &src;
+    Model *m = (Model *)handle;
+    const std::string n(name);
+    const int64_t T = m->T, Tf = 8 * T, Tt = m->Lt[4];
+    static const int ch[4] = {48, 96, 192, 384}, fr[4] = {512, 128, 32, 8};
+    *ptr_dev = nullptr;
+    if (n == "x0") { *ptr_dev = m->w_x0; *numel_per_item = 4 * 2048 * T; }
+    else if (n == "xt0") { *ptr_dev = m->w_xt0; *numel_per_item = 2 * (int64_t)m->SL; }
+    else if (n == "yspec") { *ptr_dev = m->w_yspec; *numel_per_item = 4 * (int64_t)m->S * 2048 * T; }
+    else if (n == "ytime") { *ptr_dev = m->w_ytime; *numel_per_item = 2 * (int64_t)m->S * m->SL; }
+    else if (n == "tr_f") { *ptr_dev = m->w_tr_x[0][1]; *numel_per_item = 512 * Tf; }   // 5 layers: ends in buffer 1
+    else if (n == "tr_t") { *ptr_dev = m->w_tr_x[1][1]; *numel_per_item = 512 * Tt; }
+    else if (n.size() == 4 && n.compare(0, 3, "enc") == 0 && n[3] >= '0' && n[3] <= '3') {
+        const int i = n[3] - '0'; *ptr_dev = m->w_skip[i]; *numel_per_item = (int64_t)ch[i] * fr[i] * T;
+    } else if (n.size() == 5 && n.compare(0, 4, "tenc") == 0 && n[4] >= '0' && n[4] <= '3') {
+        const int i = n[4] - '0'; *ptr_dev = m->w_skip_t[i]; *numel_per_item = (int64_t)ch[i] * m->Lt[i + 1];
+    }
+    if (!*ptr_dev) return set_error(MI_EINVAL, "mi_model_tap: unknown tap '%s'", name);
+    if (dst_dev) {
+        MI_REQUIRE(B >= 1 && B <= m->cfg.max_batch, "mi_model_tap: batch %d out of range", B);
+        MI_HIP(hipMemcpyAsync(dst_dev, src, sizeof(float) * (size_t)B * *numel_per_item, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    }
+    return MI_OK;
+}
+
+int64_t mi_model_device_bytes(void *handle) { return handle ? ((Model *)handle)->device_bytes : 0; }
+
+int mi_segments_gather(const float *track_dev, int64_t track_len, int32_t channels, const int64_t *starts_dev, int32_t B,
+                       int32_t valid, float *seg_dev, void *stream) {
+    MI_REQUIRE(track_dev && starts_dev && seg_dev && B > 0 && valid > 0 && channels > 0, "mi_segments_gather: bad argument");
+    return launch_segments_gather(track_dev, track_len, channels, starts_dev, B, valid, seg_dev, (hipStream_t)stream);
+}
+
+int mi_ola_accumulate(float *acc_dev, int64_t acc_len, int32_t rows, const float *model_out_dev, int32_t valid,
+                      const int64_t *offs_dev, const int32_t *lens_dev, const int32_t *trim_dev, int32_t B, int64_t span_lo,
+                      int64_t span_hi, const float *weight_dev, void *stream) {
+    MI_REQUIRE(acc_dev && model_out_dev && offs_dev && lens_dev && trim_dev && weight_dev && B > 0, "mi_ola_accumulate: bad argument");
+    return launch_ola_accumulate(acc_dev, acc_len, rows, model_out_dev, valid, offs_dev, lens_dev, trim_dev, B, span_lo, span_hi,
+                                 weight_dev, (hipStream_t)stream);
+}
+
+int mi_ola_finish(float *acc_dev, int64_t acc_len, int32_t rows, int64_t acc_off0, const int64_t *offs_dev,
+                  const int32_t *lens_dev, int32_t n_segments, int32_t max_len, const float *weight_dev, void *stream) {
+    MI_REQUIRE(acc_dev && offs_dev && lens_dev && weight_dev && n_segments > 0, "mi_ola_finish: bad argument");
+    return launch_ola_finish(acc_dev, acc_len, rows, acc_off0, offs_dev, lens_dev, n_segments, max_len, weight_dev,
+                             (hipStream_t)stream);
+}
+
+// Kernel-level entry points.  They allocate their scratch with hipMalloc and free it after a
+// stream synchronise: convenient for parity tests, not meant for the hot loop.
+int mi_stft_cac(const float *mix_dev, int32_t B, int32_t L, float *cac_dev, void *stream) {
+    MI_REQUIRE(mix_dev && cac_dev && B > 0 && L > 4096, "mi_stft_cac: bad argument");
+    FftTables tb;
+    MI_TRY(get_tables(&tb));
+    const int T = (L + 1023) / 1024;
+    float *zt = nullptr; double *stats = nullptr;
+    MI_HIP(hipMalloc((void **)&zt, (size_t)B * T * 4 * 2048 * 4));
+    MI_HIP(hipMalloc((void **)&stats, sizeof(double) * 2 * kStatSlots * B));
+    hipStream_t st = (hipStream_t)stream;
+    int r = MI_OK;
+    if (hipMemsetAsync(stats, 0, sizeof(double) * 2 * kStatSlots * B, st) != hipSuccess) r = set_error(MI_EHIP, "memset failed");
+    if (r == MI_OK) r = launch_stft_frames(mix_dev, B, L, tb, zt, stats, st);
+    if (r == MI_OK) r = launch_cac_transpose(zt, B, T, nullptr, cac_dev, st);
+    (void)hipStreamSynchronize(st);
+    (void)hipFree(zt); (void)hipFree(stats);
+    return r;
+}
+
+int mi_istft_cac(const float *x_dev, int32_t B, int32_t S, int32_t L, float *wav_dev, void *stream) {
+    MI_REQUIRE(x_dev && wav_dev && B > 0 && S > 0 && L > 4096, "mi_istft_cac: bad argument");
+    FftTables tb;
+    MI_TRY(get_tables(&tb));
+    const int T = (L + 1023) / 1024;
+    float *yt = nullptr, *fr = nullptr;
+    MI_HIP(hipMalloc((void **)&yt, (size_t)B * S * T * 4 * 2048 * 4));
+    MI_HIP(hipMalloc((void **)&fr, (size_t)B * S * T * 2 * 4096 * 4));
+    hipStream_t st = (hipStream_t)stream;
+    const int r = launch_istft(x_dev, B, S, L, nullptr, nullptr, nullptr, tb, yt, fr, wav_dev, st);
+    (void)hipStreamSynchronize(st);
+    (void)hipFree(yt); (void)hipFree(fr);
+    return r;
+}
+
+int mi_conv_forward(const struct mi_conv_desc *desc, void *stream) {
+    MI_REQUIRE(desc, "mi_conv_forward: null descriptor");
+    return launch_conv(*desc, (hipStream_t)stream);
+}
+
+int mi_attention(const float *q_dev, const float *k_dev, const float *v_dev, float *o_dev, int32_t B, int32_t heads, int32_t Tq,
+                 int32_t Tk, int64_t q_batch_stride, int64_t kv_batch_stride, int64_t o_batch_stride, void *stream) {
+    MI_REQUIRE(q_dev && k_dev && v_dev && o_dev && B > 0 && heads > 0 && Tq > 0 && Tk > 0, "mi_attention: bad argument");
+    return launch_attention(q_dev, k_dev, v_dev, o_dev, B, heads, Tq, Tk, q_batch_stride, kv_batch_stride, o_batch_stride,
+                            (hipStream_t)stream);
+}
+
+int mi_layernorm_cf(const float *x_dev, int32_t B, int32_t C, int32_t T, const float *w_dev, const float *b_dev,
+                    const float *add_dev, float *y_dev, void *stream) {
+    MI_REQUIRE(x_dev && w_dev && b_dev && y_dev, "mi_layernorm_cf: null argument");
+    return launch_layernorm_cf(x_dev, B, C, T, w_dev, b_dev, add_dev, y_dev, (hipStream_t)stream);
+}
+
+}  // extern "C"

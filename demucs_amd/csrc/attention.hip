@@ -1,0 +1,132 @@
+// Multi-head attention core  O = softmax(Q^T K / 8) V  on channel-first tensors, fp32 MFMA.
+//
+// Stands in for the attention inside nn.MultiheadAttention as called by the reference
+// (demucs/transformer.py:418-419,506; 8 heads x 64, no mask, eval mode).
+//
+// Layout: q[b][h*64 + d][tq], k/v[b][h*64 + d][tk] (tokens contiguous), o like q.
+// Workgroup = 4 waves x 32 queries.  Per 32-key sub-tile a wave computes the TRANSPOSED score
+// tile S^T[key][query] = K^T Q (keys on MFMA rows, queries on lanes), so that after the online
+// softmax the 16 accumulator registers of a lane ARE the B operand of the second product
+// O^T[d][query] += V[d][key] P^T[key][query]: no LDS round trip, no cross-lane movement; the
+// k order of that product is permuted to the accumulator row map (key = (s&3) + 8(s>>2) + 4h).
+#include "common.h"
+#include "kernels.h"
+
+namespace mi {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int HD = 64;       // head dim
+constexpr int KT = 64;       // keys per LDS tile
+constexpr int VLD = KT + 1;  // V tile row stride (A-operand reads walk rows: odd stride = no bank conflicts)
+
+__global__ __launch_bounds__(256) void attention_kernel(const float *__restrict__ q, const float *__restrict__ k,
+                                                        const float *__restrict__ v, float *__restrict__ o, int Tq, int Tk,
+                                                        int64_t q_bs, int64_t kv_bs, int64_t o_bs) {
+    __shared__ float Ks[HD][KT];
+    __shared__ float Vs[HD][VLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int head = blockIdx.y, b = blockIdx.z;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const float *qp = q + (size_t)b * q_bs + (size_t)head * HD * Tq;
+    const float *kp = k + (size_t)b * kv_bs + (size_t)head * HD * Tk;
+    const float *vp = v + (size_t)b * kv_bs + (size_t)head * HD * Tk;
+
+    // Q fragment (B operand of S^T = K^T Q): lane (query li, half lh) holds Q[d = 2s + lh][q0 + li] / 8
+    const int qi = q0 + li;
+    const bool qok = qi < Tq;
+    float qreg[32];
+#pragma unroll
+    for (int s = 0; s < 32; ++s) qreg[s] = qok ? qp[(size_t)(2 * s + lh) * Tq + qi] * 0.125f : 0.f;
+
+    f32x16 oacc[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { oacc[0][r] = 0.f; oacc[1][r] = 0.f; }
+    float mrun = -INFINITY, lrun = 0.f;     // running max (both halves agree) and this half's partial sum
+
+    for (int k0 = 0; k0 < Tk; k0 += KT) {
+        __syncthreads();                     // previous tile fully consumed
+        // stage K and V tiles: 64 rows x 64 keys each, float4 global loads
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int idx = tid + 256 * it;  // 0..1023
+            const int r = idx >> 4, c4 = (idx & 15) * 4;
+            float4 kv4 = make_float4(0.f, 0.f, 0.f, 0.f), vv4 = kv4;
+            if (k0 + c4 + 3 < Tk) {
+                kv4 = *reinterpret_cast<const float4 *>(kp + (size_t)r * Tk + k0 + c4);
+                vv4 = *reinterpret_cast<const float4 *>(vp + (size_t)r * Tk + k0 + c4);
+            } else {
+                float tk[4] = {0, 0, 0, 0}, tv[4] = {0, 0, 0, 0};
+                for (int e = 0; e < 4; ++e)
+                    if (k0 + c4 + e < Tk) { tk[e] = kp[(size_t)r * Tk + k0 + c4 + e]; tv[e] = vp[(size_t)r * Tk + k0 + c4 + e]; }
+                kv4 = make_float4(tk[0], tk[1], tk[2], tk[3]); vv4 = make_float4(tv[0], tv[1], tv[2], tv[3]);
+            }
+            *reinterpret_cast<float4 *>(&Ks[r][c4]) = kv4;
+            Vs[r][c4] = vv4.x; Vs[r][c4 + 1] = vv4.y; Vs[r][c4 + 2] = vv4.z; Vs[r][c4 + 3] = vv4.w;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int kb = sub * 32;
+            // S^T[key][query]: A = K^T (lane: key li, k = d = 2s + lh), B = Q
+            f32x16 sacc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 32; ++s)
+                sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[2 * s + lh][kb + li], qreg[s], sacc, 0, 0, 0);
+            // register r of lane (li, lh) is key kb + (r&3) + 8(r>>2) + 4 lh, query li
+            float mloc = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = k0 + kb + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (key >= Tk) sacc[r] = -INFINITY;
+                mloc = fmaxf(mloc, sacc[r]);
+            }
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+            const float mnew = fmaxf(mrun, mloc);
+            const float alpha = (mrun == -INFINITY) ? 0.f : expf(mrun - mnew);
+            float psum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = (sacc[r] == -INFINITY) ? 0.f : expf(sacc[r] - mnew);
+                sacc[r] = p;
+                psum += p;
+            }
+            lrun = lrun * alpha + psum;
+            mrun = mnew;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { oacc[0][r] *= alpha; oacc[1][r] *= alpha; }
+            // O^T[d][query] += V[d][key] P^T[key][query]: A = V (lane: d = dt*32 + li, k = key(s, lh)), B = P regs
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const int kc = kb + (s & 3) + 8 * (s >> 2) + 4 * lh;
+                oacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[li][kc], sacc[s], oacc[0], 0, 0, 0);
+                oacc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[32 + li][kc], sacc[s], oacc[1], 0, 0, 0);
+            }
+        }
+    }
+    const float ltot = lrun + __shfl_xor(lrun, 32);
+    const float inv = 1.0f / ltot;
+    if (qok) {
+        float *op = o + (size_t)b * o_bs + (size_t)head * HD * Tq + qi;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int dd = dt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                op[(size_t)dd * Tq] = oacc[dt][r] * inv;
+            }
+    }
+}
+
+int launch_attention(const float *q, const float *k, const float *v, float *o, int B, int heads, int Tq, int Tk, int64_t q_bs,
+                     int64_t kv_bs, int64_t o_bs, hipStream_t st) {
+    MI_REQUIRE(Tk % 4 == 0, "attention: Tk %% 4 != 0 (%d)", Tk);
+    MI_REQUIRE(((uintptr_t)k & 15) == 0 && ((uintptr_t)v & 15) == 0 && kv_bs % 4 == 0, "attention: k/v must be 16-byte aligned");
+    hipLaunchKernelGGL(attention_kernel, dim3(ceil_div(Tq, 128), heads, B), dim3(256), 0, st, q, k, v, o, Tq, Tk, q_bs, kv_bs, o_bs);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+
+}  // namespace mi

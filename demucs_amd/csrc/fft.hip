@@ -1,0 +1,308 @@
+// STFT / iSTFT for the HTDemucs segment forward on gfx950.
+//
+// Replaces `_spec`/`_magnitude` and `_mask`/`_ispec` (reference: demucs/htdemucs.py:420-471,
+// demucs/spec.py:11-47): n_fft 4096, hop 1024, periodic Hann, normalized, centre reflect padding.
+//
+// One 256-thread workgroup computes one 4096-point complex FFT entirely in LDS (Stockham
+// autosort, three radix-16 passes, twiddles staged in LDS).  The two audio channels of a frame
+// are packed as real/imaginary parts of ONE complex transform, halving the FFT count.
+// Layouts:   frame-major scratch  zt[b][t][4][2048]   (coalesced frame stores), then a tiled
+// transpose applies the per-item normalisation and writes the conv layout x[b][4][2048][T].
+#include "common.h"
+#include "kernels.h"
+
+namespace mi {
+
+constexpr int kN = 4096;
+constexpr int kHop = 1024;
+constexpr int kBins = 2048;
+__device__ __forceinline__ int lpad(int i) { return i + (i >> 5); }   // LDS index padding (bank spread)
+constexpr int kLdsN = kN + kN / 32;
+
+struct cf { float x, y; };
+__device__ __forceinline__ cf operator+(cf a, cf b) { return {a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ cf operator-(cf a, cf b) { return {a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ cf cmul(cf a, cf b) { return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+
+template <bool INV>
+__device__ __forceinline__ void dft4(cf &a, cf &b, cf &c, cf &d) {
+    cf t0 = a + c, t1 = a - c, t2 = b + d, t3 = b - d;
+    cf jt3 = INV ? cf{-t3.y, t3.x} : cf{t3.y, -t3.x};   // (-i)*t3 forward, (+i)*t3 inverse
+    a = t0 + t2; c = t0 - t2; b = t1 + jt3; d = t1 - jt3;
+}
+
+// in-register 16-point DFT; result X[k1 + 4*k2] is left in u[4*k1 + k2]
+template <bool INV>
+__device__ __forceinline__ void dft16(cf (&u)[16]) {
+#pragma unroll
+    for (int n2 = 0; n2 < 4; ++n2) dft4<INV>(u[n2], u[4 + n2], u[8 + n2], u[12 + n2]);
+    // W16^m, m = n2*k1
+    const float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f, r2 = 0.70710678118654752440f;
+    const cf w1 = {c1, INV ? s1 : -s1}, w2 = {r2, INV ? r2 : -r2}, w3 = {s1, INV ? c1 : -c1};
+    const cf w4 = {0.f, INV ? 1.f : -1.f}, w6 = {-r2, INV ? r2 : -r2}, w9 = {-c1, INV ? -s1 : s1};
+    u[4 * 1 + 1] = cmul(u[4 * 1 + 1], w1); u[4 * 1 + 2] = cmul(u[4 * 1 + 2], w2); u[4 * 1 + 3] = cmul(u[4 * 1 + 3], w3);
+    u[4 * 2 + 1] = cmul(u[4 * 2 + 1], w2); u[4 * 2 + 2] = cmul(u[4 * 2 + 2], w4); u[4 * 2 + 3] = cmul(u[4 * 2 + 3], w6);
+    u[4 * 3 + 1] = cmul(u[4 * 3 + 1], w3); u[4 * 3 + 2] = cmul(u[4 * 3 + 2], w6); u[4 * 3 + 3] = cmul(u[4 * 3 + 3], w9);
+#pragma unroll
+    for (int k1 = 0; k1 < 4; ++k1) dft4<INV>(u[4 * k1], u[4 * k1 + 1], u[4 * k1 + 2], u[4 * k1 + 3]);
+}
+
+// One Stockham pass: u[] already holds x[i + 256 r] (r = 0..15) of thread i; P = 1, 16 or 256.
+// Writes the pass output to LDS re/im (natural order after the P = 256 pass).
+template <bool INV, int P>
+__device__ __forceinline__ void stockham_pass(cf (&u)[16], int i, float *re, float *im, const float *twr, const float *twi) {
+    const int k = i & (P - 1);
+    if (P > 1) {
+        const int step = k * (kN / (16 * P));
+#pragma unroll
+        for (int r = 1; r < 16; ++r) {
+            // half table: W[n + 2048] = -W[n]
+            const int n = step * r, h = n & (kN / 2 - 1);
+            const float sg = (n & (kN / 2)) ? -1.f : 1.f;
+            cf w = {sg * twr[h], (INV ? -sg : sg) * twi[h]};
+            u[r] = cmul(u[r], w);
+        }
+    }
+    dft16<INV>(u);
+    const int j = (i - k) * 16 + k;
+#pragma unroll
+    for (int k1 = 0; k1 < 4; ++k1)
+#pragma unroll
+        for (int k2 = 0; k2 < 4; ++k2) {
+            const int r = k1 + 4 * k2;
+            const int o = lpad(j + r * P);
+            re[o] = u[4 * k1 + k2].x;
+            im[o] = u[4 * k1 + k2].y;
+        }
+}
+
+template <bool INV>
+__device__ __forceinline__ void load_pass_input(cf (&u)[16], int i, const float *re, const float *im) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int o = lpad(i + 256 * r);
+        u[r] = {re[o], im[o]};
+    }
+}
+
+// passes P=16 and P=256 reading from / writing to LDS (pass P=1 is done by the caller)
+template <bool INV>
+__device__ __forceinline__ void fft_tail(cf (&u)[16], int i, float *re, float *im, const float *twr, const float *twi) {
+    __syncthreads();
+    load_pass_input<INV>(u, i, re, im);
+    __syncthreads();
+    stockham_pass<INV, 16>(u, i, re, im, twr, twi);
+    __syncthreads();
+    load_pass_input<INV>(u, i, re, im);
+    __syncthreads();
+    stockham_pass<INV, 256>(u, i, re, im, twr, twi);
+    __syncthreads();
+}
+
+__device__ __forceinline__ void stage_twiddles(const float2 *tw, float *twr, float *twi, int i) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        float2 w = tw[i + 256 * r];
+        twr[i + 256 * r] = w.x;
+        twi[i + 256 * r] = w.y;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// STFT: grid (T, B), block 256.  mix (B,2,L) -> zt[b][t][4][2048] + per-item (sum, sumsq) in fp64.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void stft_frames_kernel(const float *__restrict__ mix, int L, int T, const float *__restrict__ window,
+                                                          const float2 *__restrict__ tw, float *__restrict__ zt,
+                                                          double *__restrict__ stats) {
+    __shared__ float re[kLdsN], im[kLdsN], twr[kN / 2], twi[kN / 2];
+    __shared__ double red[8];
+    const int i = threadIdx.x, t = blockIdx.x, b = blockIdx.y;
+    stage_twiddles(tw, twr, twi, i);
+    const float *x0 = mix + (size_t)b * 2 * L, *x1 = x0 + L;
+    // frame t of the kept range is frame t+2 of th.stft: padded-signal samples [(t+2)*1024 - 2048, +4096)
+    // of x1 = reflect_pad(mix, 1536, 1536 + T*1024 - L)  (htdemucs.py:433-435); the centre padding of
+    // th.stft itself never reaches the kept frames.
+    const int L1 = L + 1536 + (1536 + T * kHop - L);
+    cf u[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int p = i + 256 * r;
+        int q = t * kHop + p;                       // index into x1 (always within [0, L1) for kept frames)
+        if (q >= L1) q = 2 * (L1 - 1) - q;          // defensive: th.stft centre reflect
+        int s = q - 1536;
+        if (s < 0) s = -s;
+        if (s >= L) s = 2 * (L - 1) - s;
+        const float w = window[p];
+        u[r] = {w * x0[s], w * x1[s]};
+    }
+    __syncthreads();   // twiddles staged
+    stockham_pass<false, 1>(u, i, re, im, twr, twi);
+    fft_tail<false>(u, i, re, im, twr, twi);
+    // split the packed transform: X0 = (Z[k] + conj Z[N-k]) / 2, X1 = (Z[k] - conj Z[N-k]) / (2i); x 1/sqrt(N)
+    float *o = zt + ((size_t)b * T + t) * 4 * kBins;
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int k = i + 256 * r;
+        const int km = (kN - k) & (kN - 1);
+        const float ar = re[lpad(k)], ai = im[lpad(k)], br = re[lpad(km)], bi = im[lpad(km)];
+        const float sc = 0.5f / 64.0f;
+        const float v0 = (ar + br) * sc, v1 = (ai - bi) * sc, v2 = (ai + bi) * sc, v3 = (br - ar) * sc;
+        o[k] = v0; o[kBins + k] = v1; o[2 * kBins + k] = v2; o[3 * kBins + k] = v3;
+        s1 += (double)v0 + (double)v1 + (double)v2 + (double)v3;
+        s2 += (double)v0 * v0 + (double)v1 * v1 + (double)v2 * v2 + (double)v3 * v3;
+    }
+    // block reduce -> one fp64 atomic pair per workgroup, spread over slots
+    for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_down(s1, off); s2 += __shfl_down(s2, off); }
+    if ((i & 63) == 0) { red[(i >> 6) * 2] = s1; red[(i >> 6) * 2 + 1] = s2; }
+    __syncthreads();
+    if (i == 0) {
+        double a = red[0] + red[2] + red[4] + red[6], c = red[1] + red[3] + red[5] + red[7];
+        double *dst = stats + ((size_t)b * kStatSlots + (t % kStatSlots)) * 2;
+        atomicAdd(dst, a);
+        atomicAdd(dst + 1, c);
+    }
+}
+
+// zt[b][t][4][2048] -> x[b][4][2048][T] with optional (v - mean) * inv, 32x32 LDS tiles.
+// grid (ceil(T/32), 2048/32, B*4)
+__global__ __launch_bounds__(256) void cac_transpose_kernel(const float *__restrict__ zt, int T, const float2 *__restrict__ norm,
+                                                            float *__restrict__ x) {
+    __shared__ float tile[32][33];
+    const int bc = blockIdx.z, b = bc >> 2, c = bc & 3;
+    const int t0 = blockIdx.x * 32, k0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    float mean = 0.f, inv = 1.f;
+    if (norm) { float2 m = norm[b]; mean = m.x; inv = m.y; }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int t = t0 + ty + 8 * r;
+        if (t < T) tile[ty + 8 * r][tx] = zt[(((size_t)b * T + t) * 4 + c) * kBins + k0 + tx];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int k = k0 + ty + 8 * r, t = t0 + tx;
+        if (t < T) x[(((size_t)b * 4 + c) * kBins + k) * T + t] = (tile[tx][ty + 8 * r] - mean) * inv;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// iSTFT.  (1) y[b][S*4][2048][T] (decoder output, CaC) -> frame-major yt[b][s][t][4][2048] with
+//             the de-normalisation  v*std + mean  (htdemucs.py:625-626) folded in;
+//         (2) one inverse FFT per (b, s, t): both channels packed, x sqrt(N)/N, x window
+//             -> fr[b][s][t][2][4096];
+//         (3) overlap-add gather, / window envelope, crop, + time branch * stdt + meant.
+// ---------------------------------------------------------------------------------------------
+// grid (ceil(T/32), 2048/32, B*S*4)
+__global__ __launch_bounds__(256) void spec_transpose_kernel(const float *__restrict__ y, int T, int S4, const float2 *__restrict__ denorm,
+                                                             float *__restrict__ yt) {
+    __shared__ float tile[32][33];
+    const int bc = blockIdx.z, b = bc / S4, sc = bc % S4, s = sc >> 2, c = sc & 3;
+    const int t0 = blockIdx.x * 32, k0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    float mean = 0.f, std = 1.f;
+    if (denorm) { float2 m = denorm[b]; mean = m.x; std = m.y; }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int k = k0 + ty + 8 * r, t = t0 + tx;
+        if (t < T) tile[ty + 8 * r][tx] = y[(((size_t)b * S4 + sc) * kBins + k) * T + t] * std + mean;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int t = t0 + ty + 8 * r;
+        if (t < T) yt[((((size_t)b * (S4 >> 2) + s) * T + t) * 4 + c) * kBins + k0 + tx] = tile[tx][ty + 8 * r];
+    }
+}
+
+// grid (T, B*S), block 256
+__global__ __launch_bounds__(256) void istft_frames_kernel(const float *__restrict__ yt, int T, const float *__restrict__ window,
+                                                           const float2 *__restrict__ tw, float *__restrict__ fr) {
+    __shared__ float re[kLdsN], im[kLdsN], twr[kN / 2], twi[kN / 2];
+    const int i = threadIdx.x, t = blockIdx.x, bs = blockIdx.y;
+    stage_twiddles(tw, twr, twi, i);
+    const float *src = yt + ((size_t)bs * T + t) * 4 * kBins;
+    // Z[k] = X0[k] + i X1[k];  Z[N-k] = conj(X0[k]) + i conj(X1[k]);  Nyquist bin is the zero pad of
+    // htdemucs.py:444; the imaginary part of the DC bin is ignored by a C2R transform.
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int k = i + 256 * r;
+        float ar = src[k], ai = src[kBins + k], br = src[2 * kBins + k], bi = src[3 * kBins + k];
+        if (k == 0) { ai = 0.f; bi = 0.f; }
+        re[lpad(k)] = ar - bi; im[lpad(k)] = ai + br;
+        if (k > 0) { re[lpad(kN - k)] = ar + bi; im[lpad(kN - k)] = br - ai; }
+    }
+    if (i == 0) { re[lpad(kBins)] = 0.f; im[lpad(kBins)] = 0.f; }
+    __syncthreads();
+    cf u[16];
+    load_pass_input<true>(u, i, re, im);
+    __syncthreads();
+    stockham_pass<true, 1>(u, i, re, im, twr, twi);
+    fft_tail<true>(u, i, re, im, twr, twi);
+    float *dst = fr + ((size_t)bs * T + t) * 2 * kN;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int p = i + 256 * r;
+        const float w = window[p] * (1.0f / 64.0f);
+        dst[p] = re[lpad(p)] * w;
+        dst[kN + p] = im[lpad(p)] * w;
+    }
+}
+
+// out[b][s][c][n] = OLA(frames)[n] / env + (xt ? xt[b][s*2+c][n] * stdt + meant : 0)
+// grid (ceil(L/256), B*S*2)
+__global__ __launch_bounds__(256) void istft_ola_kernel(const float *__restrict__ fr, int T, int L, const float *__restrict__ env,
+                                                        const float *__restrict__ xt, const float2 *__restrict__ denorm_t, int S,
+                                                        float *__restrict__ out) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= L) return;
+    const int bsc = blockIdx.y, c = bsc & 1, bs = bsc >> 1;
+    // position in the un-trimmed overlap-add buffer: + 1536 (crop of htdemucs.py:449) + 2048 (centre trim)
+    const int u = n + 1536 + 2048;
+    const int mhi = u >> 10, r = u & 1023;
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 3; j >= 0; --j) {              // ascending frame index, like a sequential overlap-add
+        const int m = mhi - j - 2;              // data frame index (frames 0,1 and T+2,T+3 are the zero pad)
+        if (m >= 0 && m < T) acc += fr[(((size_t)bs * T + m) * 2 + c) * kN + r + 1024 * j];
+    }
+    float v = acc / env[r];
+    if (xt) {
+        const int b = bs / S;
+        const float2 d = denorm_t[b];
+        v += xt[(size_t)bsc * L + n] * d.y + d.x;
+    }
+    out[(size_t)bsc * L + n] = v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-side launchers
+// ---------------------------------------------------------------------------------------------
+int launch_stft_frames(const float *mix, int B, int L, const FftTables &tb, float *zt, double *stats, hipStream_t st) {
+    const int T = ceil_div(L, kHop);
+    MI_REQUIRE(L > 1620, "stft: segment too short for reflect padding (L=%d)", L);
+    hipLaunchKernelGGL(stft_frames_kernel, dim3(T, B), dim3(256), 0, st, mix, L, T, tb.window, tb.twiddle, zt, stats);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+
+int launch_cac_transpose(const float *zt, int B, int T, const float2 *norm, float *x, hipStream_t st) {
+    hipLaunchKernelGGL(cac_transpose_kernel, dim3(ceil_div(T, 32), kBins / 32, B * 4), dim3(256), 0, st, zt, T, norm, x);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+
+int launch_istft(const float *y, int B, int S, int L, const float2 *denorm, const float *xt, const float2 *denorm_t,
+                 const FftTables &tb, float *yt, float *fr, float *out, hipStream_t st) {
+    const int T = ceil_div(L, kHop);
+    hipLaunchKernelGGL(spec_transpose_kernel, dim3(ceil_div(T, 32), kBins / 32, B * S * 4), dim3(256), 0, st, y, T, S * 4, denorm, yt);
+    MI_CHECK_LAUNCH();
+    hipLaunchKernelGGL(istft_frames_kernel, dim3(T, B * S), dim3(256), 0, st, yt, T, tb.window, tb.twiddle, fr);
+    MI_CHECK_LAUNCH();
+    hipLaunchKernelGGL(istft_ola_kernel, dim3(ceil_div(L, 256), B * S * 2), dim3(256), 0, st, fr, T, L, tb.envelope, xt, denorm_t, S, out);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+
+}  // namespace mi

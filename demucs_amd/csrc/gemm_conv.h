@@ -1,0 +1,69 @@
+// Implicit-GEMM convolution / linear layer on the fp32 MFMA path (v_mfma_f32_32x32x2_f32).
+//
+//   Y[m][n] = epilogue( sum_k Wt[k][m] * B[k][n] ),   B[k][n] = prologue( X[gather(k, n)] )
+//
+// n enumerates output positions (b, o1, o2) of a channel-first activation tensor, k enumerates
+// (input channel, tap).  The gather is table driven (one int4 per k), so ONE kernel covers
+// Conv1d/Conv2d with stride / dilation / padding, 1x1 convs and nn.Linear on channel-first
+// tokens, and ConvTranspose(k=8, s=4) rewritten as a 4-phase GEMM with a scatter epilogue.
+#pragma once
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum mi_epilogue {
+    MI_EPI_LINEAR = 0,      /* y = [res +] [scale *] act(acc + bias)                                   */
+    MI_EPI_GLU = 1,         /* rows interleaved (a_c, g_c): y[c] = (a+ba) * sigmoid(g+bg) [+ emb[c][o1]] */
+    MI_EPI_BIAS_STATS = 2,  /* y = acc + bias, and per-row sum / sum-of-squares -> stats (fp64 atomics) */
+    MI_EPI_STATS_ONLY = 3,  /* statistics of (acc + bias) only, nothing stored                          */
+    MI_EPI_GN_GLU = 4,      /* y[c] = res + scale[c] * GLU(GroupNorm(acc + bias))  (DConv tail)         */
+    MI_EPI_CONVTR = 5       /* rows (co, phase r): y[co][4*o + r - 2] = [res +] act(acc + bias)         */
+};
+
+#define MI_FLAG_GELU 1
+#define MI_FLAG_SCALE 2
+#define MI_FLAG_RES 4
+#define MI_FLAG_EMB 8
+#define MI_FLAG_TR_FREQ 16 /* CONVTR scatters along o1 (frequency axis) instead of o2 (time axis) */
+
+typedef struct mi_ktab_entry {
+    int32_t off; /* element offset added to the column base: ci*chan_stride + d1*D2 + d2 */
+    int32_t d1;  /* i1 = o1*S1 + d1 must lie in [0, D1)                                   */
+    int32_t d2;  /* i2 = o2*S2 + d2 must lie in [0, D2)                                   */
+    int32_t ci;  /* input channel (for the per-channel prologue affine)                    */
+} mi_ktab_entry;
+
+typedef struct mi_conv_desc {
+    /* weights, packed [Kpad][Mpad] (M contiguous), zero padded */
+    const float *wt;
+    int32_t M, Mpad, K, Kpad;
+    const mi_ktab_entry *ktab; /* [Kpad] device */
+    /* input activation X[b][Cin][D1][D2] */
+    const float *x;
+    int64_t x_bstride;
+    int32_t B, D1, D2, O1, O2, S1, S2;
+    /* prologue: 0 none; 1: gelu((x - mean[row]) * rstd[row] * pro_w[ci] + pro_b[ci]) */
+    int32_t pro;
+    const float *pro_stats; /* float2 [rows] (mean, rstd) */
+    const float *pro_w, *pro_b;
+    int32_t row_mode; /* statistics row of a column: 0 -> b, 1 -> b*O1 + o1 */
+    /* epilogue */
+    int32_t epi, flags;
+    const float *bias;  /* [Mpad] packed row order */
+    const float *scale; /* LINEAR: [Mpad]; GN_GLU: [Cout] */
+    const float *res;   /* same layout as y */
+    const float *emb;   /* GLU + MI_FLAG_EMB: [Cout][O1] */
+    float *y;
+    int64_t y_bstride, y_cstride;
+    double *stats;          /* [rows][32][2] fp64 partial sums (zeroed by the caller)   */
+    const float *gn_stats;  /* float2 [rows] (mean, rstd) for MI_EPI_GN_GLU             */
+    const float *gn_w, *gn_b; /* [Mpad] packed row order                                 */
+    int32_t out_len;        /* CONVTR: valid output length along the scattered axis      */
+    int32_t tile_m;         /* 0 = choose automatically; else 32 / 64 / 96 / 128         */
+} mi_conv_desc;
+
+#ifdef __cplusplus
+}
+#endif

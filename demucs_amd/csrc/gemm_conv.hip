@@ -1,0 +1,298 @@
+// Implicit-GEMM convolution on gfx950 fp32 MFMA (see gemm_conv.h).
+//
+// Workgroup = 256 threads = 4 waves; block tile BM x 128 (BM = 32, 64, 96 or 128), K step 16,
+// LDS double buffer, global->register prefetch of tile k+1 while tile k feeds the matrix cores.
+// Both operands sit in LDS k-major ([16][BM], [16][128]) so that a 32x32x2 MFMA fragment
+// (lane l: row/col l&31, k = l>>5) is one conflict-free ds_read_b32 per operand.
+// Arithmetic is exact fp32 (v_mfma_f32_32x32x2_f32 == k-ordered fmaf chain): the <=1e-4 parity
+// target against the fp32 CPU reference leaves no room for bf16 operands.
+#include "common.h"
+#include "gemm_conv.h"
+#include "kernels.h"
+
+namespace mi {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 16;
+constexpr int BN = 128;
+
+struct ColInfo {   // decomposition of one output column n = (b, o1, o2)
+    int b, o1, o2, p;
+    bool valid;
+};
+
+__device__ __forceinline__ ColInfo decompose(int n, int N, int P, int O2) {
+    ColInfo c;
+    c.valid = n < N;
+    const int nn = c.valid ? n : 0;
+    c.b = nn / P;
+    c.p = nn - c.b * P;
+    c.o1 = c.p / O2;
+    c.o2 = c.p - c.o1 * O2;
+    return c;
+}
+
+template <int WM, int WN, int TM, int TN, int PRO, int EPI>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(const mi_conv_desc d, const int N, const int MT) {
+    constexpr int BM = WM * TM * 32;
+    static_assert(WN * TN * 32 == BN, "block N tile is 128");
+    static_assert(WM * WN == 4, "4 waves");
+    __shared__ float As[2][BK][BM];
+    __shared__ float Bs[2][BK][BN];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    // m-tile index fastest: the workgroups that share one activation tile are dispatched together
+    const int mt = blockIdx.x % MT, nt = blockIdx.x / MT;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int P = d.O1 * d.O2;
+
+    // ---- B loader: this thread owns column (tid & 127), rows khalf + 2*j ------------------------
+    const int khalf = wave >> 1;
+    const ColInfo lc = decompose(n0 + (tid & 127), N, P, d.O2);
+    const int i1b = lc.o1 * d.S1, i2b = lc.o2 * d.S2;
+    const float *xcol = d.x + (size_t)lc.b * d.x_bstride + (size_t)i1b * d.D2 + i2b;
+    float pmean = 0.f, prstd = 0.f;
+    if (PRO == 1) {
+        const int row = d.row_mode ? lc.b * d.O1 + lc.o1 : lc.b;
+        const float2 st = reinterpret_cast<const float2 *>(d.pro_stats)[row];
+        pmean = st.x; prstd = st.y;
+    }
+
+    float breg[8];
+    float4 areg[(BK * BM / 4 + 255) / 256];
+    constexpr int A_ITERS = (BK * BM / 4 + 255) / 256;
+
+    auto load_tile = [&](int kt) {
+        const int k0 = kt * BK;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = k0 + khalf + 2 * j;                    // wave-uniform -> scalar table load
+            const mi_ktab_entry e = d.ktab[k];
+            const int i1 = i1b + e.d1, i2 = i2b + e.d2;
+            const bool ok = lc.valid && (unsigned)i1 < (unsigned)d.D1 && (unsigned)i2 < (unsigned)d.D2;
+            float v = ok ? xcol[e.off] : 0.f;
+            if (PRO == 1) {
+                const float w = d.pro_w[e.ci], bb = d.pro_b[e.ci];
+                v = ok ? gelu_exact((v - pmean) * prstd * w + bb) : 0.f;
+            }
+            breg[j] = v;
+        }
+#pragma unroll
+        for (int it = 0; it < A_ITERS; ++it) {
+            const int idx = tid + it * 256;
+            if (idx < BK * BM / 4) {
+                const int r = idx / (BM / 4), c4 = idx % (BM / 4);
+                areg[it] = *reinterpret_cast<const float4 *>(d.wt + (size_t)(k0 + r) * d.Mpad + m0 + c4 * 4);
+            }
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) Bs[buf][khalf + 2 * j][tid & 127] = breg[j];
+#pragma unroll
+        for (int it = 0; it < A_ITERS; ++it) {
+            const int idx = tid + it * 256;
+            if (idx < BK * BM / 4) {
+                const int r = idx / (BM / 4), c4 = idx % (BM / 4);
+                *reinterpret_cast<float4 *>(&As[buf][r][c4 * 4]) = areg[it];
+            }
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int nk = d.Kpad / BK;
+    const int li = lane & 31, lh = lane >> 5;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) load_tile(kt + 1);
+#pragma unroll
+        for (int s = 0; s < BK / 2; ++s) {
+            float af[TM], bf[TN];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) af[a] = As[cur][2 * s + lh][(wm * TM + a) * 32 + li];
+#pragma unroll
+            for (int b = 0; b < TN; ++b) bf[b] = Bs[cur][2 * s + lh][(wn * TN + b) * 32 + li];
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[b], acc[a][b], 0, 0, 0);
+        }
+        if (kt + 1 < nk) store_tile(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue ---------------------------------------------------------------------------------
+    // acc[a][b][r] is C[m][n] with n = ncol(b) + li, m = mrow(a) + (r & 3) + 8 * (r >> 2) + 4 * lh
+    const int slot = blockIdx.x % kStatSlots;
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+        const int n = n0 + (wn * TN + b) * 32 + li;
+        const ColInfo c = decompose(n, N, P, d.O2);
+        const int row = d.row_mode ? c.b * d.O1 + c.o1 : c.b;
+        float s1 = 0.f, s2 = 0.f;
+        float gmean = 0.f, grstd = 0.f;
+        if (EPI == MI_EPI_GN_GLU) {
+            const float2 st = reinterpret_cast<const float2 *>(d.gn_stats)[row];
+            gmean = st.x; grstd = st.y;
+        }
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+            const int mbase = m0 + (wm * TM + a) * 32 + 4 * lh;
+            if (EPI == MI_EPI_LINEAR) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mbase + (r & 3) + 8 * (r >> 2);
+                    float v = acc[a][b][r] + d.bias[m];
+                    if (d.flags & MI_FLAG_GELU) v = gelu_exact(v);
+                    if (d.flags & MI_FLAG_SCALE) v *= d.scale[m];
+                    if (c.valid && m < d.M) {
+                        const size_t idx = (size_t)c.b * d.y_bstride + (size_t)m * d.y_cstride + c.p;
+                        if (d.flags & MI_FLAG_RES) v += d.res[idx];
+                        d.y[idx] = v;
+                    }
+                }
+            } else if (EPI == MI_EPI_GLU || EPI == MI_EPI_GN_GLU) {
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const int m = mbase + (r & 3) + 8 * (r >> 2);   // even row: value, m+1: gate
+                    float va = acc[a][b][r] + d.bias[m], vg = acc[a][b][r + 1] + d.bias[m + 1];
+                    if (EPI == MI_EPI_GN_GLU) {
+                        va = (va - gmean) * grstd * d.gn_w[m] + d.gn_b[m];
+                        vg = (vg - gmean) * grstd * d.gn_w[m + 1] + d.gn_b[m + 1];
+                    }
+                    float v = va * sigmoid_f(vg);
+                    const int ch = m >> 1;
+                    if (c.valid && m < d.M) {
+                        const size_t idx = (size_t)c.b * d.y_bstride + (size_t)ch * d.y_cstride + c.p;
+                        if (EPI == MI_EPI_GN_GLU) v = d.res[idx] + d.scale[ch] * v;
+                        else if (d.flags & MI_FLAG_EMB) v += d.emb[ch * d.O1 + c.o1];
+                        d.y[idx] = v;
+                    }
+                }
+            } else if (EPI == MI_EPI_BIAS_STATS || EPI == MI_EPI_STATS_ONLY) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mbase + (r & 3) + 8 * (r >> 2);
+                    const float v = acc[a][b][r] + d.bias[m];
+                    if (c.valid && m < d.M) {
+                        if (EPI == MI_EPI_BIAS_STATS)
+                            d.y[(size_t)c.b * d.y_bstride + (size_t)m * d.y_cstride + c.p] = v;
+                        s1 += v; s2 += v * v;
+                    }
+                }
+            } else if (EPI == MI_EPI_CONVTR) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mbase + (r & 3) + 8 * (r >> 2);
+                    const int co = m >> 2, ph = m & 3;
+                    float v = acc[a][b][r] + d.bias[m];
+                    if (d.flags & MI_FLAG_GELU) v = gelu_exact(v);
+                    const int o = 4 * ((d.flags & MI_FLAG_TR_FREQ) ? c.o1 : c.o2) + ph - 2;
+                    if (c.valid && m < d.M && o >= 0 && o < d.out_len) {
+                        const size_t pos = (d.flags & MI_FLAG_TR_FREQ) ? (size_t)o * d.O2 + c.o2 : (size_t)o;
+                        const size_t idx = (size_t)c.b * d.y_bstride + (size_t)co * d.y_cstride + pos;
+                        if (d.flags & MI_FLAG_RES) v += d.res[idx];
+                        d.y[idx] = v;
+                    }
+                }
+            }
+        }
+        if (EPI == MI_EPI_BIAS_STATS || EPI == MI_EPI_STATS_ONLY) {
+            // a wave's 32 columns span at most two statistics rows (O2 >= 32): reduce both groups
+            double t1 = (double)s1, t2 = (double)s2;
+            t1 += __shfl_xor(t1, 32); t2 += __shfl_xor(t2, 32);          // the two lane halves share a column
+            const int rid = c.valid ? row : -1;
+            const int row0 = __shfl(rid, 0);
+            int rowB = rid;
+            double a1 = (rid == row0 && rid >= 0) ? t1 : 0.0, a2 = (rid == row0 && rid >= 0) ? t2 : 0.0;
+            double b1 = (rid != row0 && rid >= 0) ? t1 : 0.0, b2 = (rid != row0 && rid >= 0) ? t2 : 0.0;
+#pragma unroll
+            for (int off = 16; off > 0; off >>= 1) {
+                a1 += __shfl_xor(a1, off); a2 += __shfl_xor(a2, off);
+                b1 += __shfl_xor(b1, off); b2 += __shfl_xor(b2, off);
+                rowB = max(rowB, __shfl_xor(rowB, off));
+            }
+            if (lane == 0 && row0 >= 0) {
+                double *dst = d.stats + ((size_t)row0 * kStatSlots + slot) * 2;
+                atomicAdd(dst, a1); atomicAdd(dst + 1, a2);
+                if (rowB != row0) {
+                    dst = d.stats + ((size_t)rowB * kStatSlots + slot) * 2;
+                    atomicAdd(dst, b1); atomicAdd(dst + 1, b2);
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+template <int WM, int WN, int TM, int TN, int PRO, int EPI>
+static int launch_cfg(const mi_conv_desc &d, hipStream_t st) {
+    constexpr int BM = WM * TM * 32;
+    const int64_t N64 = (int64_t)d.B * d.O1 * d.O2;
+    MI_REQUIRE(N64 < (1ll << 31) - 256, "conv: too many output positions (%lld)", (long long)N64);
+    MI_REQUIRE(d.Mpad % BM == 0, "conv: Mpad %d not a multiple of the %d-row tile", d.Mpad, BM);
+    const int N = (int)N64, MT = d.Mpad / BM, NT = ceil_div(N, BN);
+    hipLaunchKernelGGL((conv_gemm_kernel<WM, WN, TM, TN, PRO, EPI>), dim3((unsigned)MT * NT), dim3(256), 0, st, d, N, MT);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+
+template <int PRO, int EPI>
+static int launch_tile(const mi_conv_desc &d, int tile, hipStream_t st) {
+    switch (tile) {
+        case 128: return launch_cfg<2, 2, 2, 2, PRO, EPI>(d, st);
+        case 96: return launch_cfg<1, 4, 3, 1, PRO, EPI>(d, st);
+        case 64: return launch_cfg<1, 4, 2, 1, PRO, EPI>(d, st);
+        case 32: return launch_cfg<1, 4, 1, 1, PRO, EPI>(d, st);
+    }
+    return set_error(MI_EINVAL, "conv: unsupported tile_m %d", tile);
+}
+
+int conv_pick_tile(int M) {
+    if (M <= 32) return 32;
+    if (M <= 64) return 64;
+    if (M % 128 == 0) return 128;
+    if (M % 96 == 0) return 96;
+    if (M <= 96) return 96;
+    return 128;
+}
+
+int launch_conv(const mi_conv_desc &d, hipStream_t st) {
+    MI_REQUIRE(d.Kpad % BK == 0 && d.Kpad >= BK, "conv: Kpad %d must be a positive multiple of %d", d.Kpad, BK);
+    MI_REQUIRE(d.Mpad % 4 == 0, "conv: Mpad %d must be a multiple of 4", d.Mpad);
+    MI_REQUIRE(d.O2 >= 32 || d.row_mode == 0 || (d.epi != MI_EPI_BIAS_STATS && d.epi != MI_EPI_STATS_ONLY),
+               "conv: statistics epilogue needs O2 >= 32");
+    const int tile = d.tile_m ? d.tile_m : conv_pick_tile(d.M);
+    if (d.pro == 0) {
+        switch (d.epi) {
+            case MI_EPI_LINEAR: return launch_tile<0, MI_EPI_LINEAR>(d, tile, st);
+            case MI_EPI_GLU: return launch_tile<0, MI_EPI_GLU>(d, tile, st);
+            case MI_EPI_BIAS_STATS: return launch_tile<0, MI_EPI_BIAS_STATS>(d, tile, st);
+            case MI_EPI_CONVTR: return launch_tile<0, MI_EPI_CONVTR>(d, tile, st);
+        }
+    } else if (d.pro == 1) {
+        switch (d.epi) {
+            case MI_EPI_STATS_ONLY: return launch_tile<1, MI_EPI_STATS_ONLY>(d, tile, st);
+            case MI_EPI_GN_GLU: return launch_tile<1, MI_EPI_GN_GLU>(d, tile, st);
+        }
+    }
+    return set_error(MI_EINVAL, "conv: unsupported prologue/epilogue combination (%d, %d)", d.pro, d.epi);
+}
+
+}  // namespace mi

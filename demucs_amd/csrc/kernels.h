@@ -1,0 +1,49 @@
+// Internal launcher declarations shared by the engine's translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gemm_conv.h"
+
+namespace mi {
+
+struct FftTables {
+    const float *window;    // [4096] periodic Hann, float32 like th.hann_window
+    const float2 *twiddle;  // [2048] exp(-2 pi i n / 4096)
+    const float *envelope;  // [1024] sum_j window^2[r + 1024 j]
+};
+
+// fft.hip
+int launch_stft_frames(const float *mix, int B, int L, const FftTables &tb, float *zt, double *stats, hipStream_t st);
+int launch_cac_transpose(const float *zt, int B, int T, const float2 *norm, float *x, hipStream_t st);
+int launch_istft(const float *y, int B, int S, int L, const float2 *denorm, const float *xt, const float2 *denorm_t,
+                 const FftTables &tb, float *yt, float *fr, float *out, hipStream_t st);
+
+// norms.hip
+int launch_row_stats(const float *x, int rows, int64_t count, int64_t row_stride, double *stats, hipStream_t st);
+int launch_finalize_stats(const double *stats, int rows, double count, float eps, int mode, float2 *out_a, float2 *out_b,
+                          hipStream_t st);
+int launch_row_affine(const float *x, int rows, int64_t count, const float2 *norm, float *y, hipStream_t st);
+int launch_layernorm_cf(const float *x, int B, int C, int T, const float *w, const float *b, const float *pe, float *y,
+                        hipStream_t st);
+int launch_gn_apply_cf(const float *x, int B, int C, int T, const float2 *stats, const float *w, const float *b, float *y,
+                       hipStream_t st);
+
+// gemm_conv.hip
+int launch_conv(const mi_conv_desc &d, hipStream_t st);
+int conv_pick_tile(int M);
+
+// attention.hip
+int launch_attention(const float *q, const float *k, const float *v, float *o, int B, int heads, int Tq, int Tk, int64_t q_bs,
+                     int64_t kv_bs, int64_t o_bs, hipStream_t st);
+
+// ola.hip
+int launch_segments_gather(const float *track, int64_t track_len, int channels, const int64_t *starts_dev, int B, int valid,
+                           float *seg, hipStream_t st);
+int launch_ola_accumulate(float *acc, int64_t acc_len, int rows, const float *model_out, int valid, const int64_t *offs_dev,
+                          const int32_t *lens_dev, const int32_t *trim_dev, int B, int64_t span_lo, int64_t span_hi,
+                          const float *weight, hipStream_t st);
+int launch_ola_finish(float *acc, int64_t acc_len, int rows, int64_t acc_off0, const int64_t *offs_dev, const int32_t *lens_dev,
+                      int n_segments, int max_len, const float *weight, hipStream_t st);
+
+}  // namespace mi

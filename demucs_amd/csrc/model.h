@@ -1,0 +1,90 @@
+// Engine state: packed weights, gather tables, workspace.  One Model per (weights, device).
+#pragma once
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "gemm_conv.h"
+#include "kernels.h"
+
+namespace mi {
+
+struct WeightTable;
+struct Gather;
+struct Geo;
+
+struct PackedConv {
+    float *wt = nullptr, *bias = nullptr;
+    int M = 0, Mpad = 0, K = 0, Kpad = 0, tile = 0;
+};
+
+struct DConvLayerW {
+    PackedConv conv3, conv1;
+    mi_ktab_entry *ktab3 = nullptr, *ktab1 = nullptr;
+    float *gn1_w = nullptr, *gn1_b = nullptr, *gn2_w = nullptr, *gn2_b = nullptr, *ls = nullptr;
+};
+struct DConvW { DConvLayerW l[2]; };
+
+struct EncW {
+    PackedConv conv, rewrite;
+    mi_ktab_entry *ktab_conv = nullptr, *ktab_rw = nullptr;
+    DConvW dconv;
+};
+struct DecW {
+    PackedConv rewrite, convtr;
+    mi_ktab_entry *ktab_rw = nullptr, *ktab_tr = nullptr;
+    DConvW dconv;
+};
+struct TrLayerW {
+    PackedConv qkv_proj, q_proj, kv_proj, out_proj, lin1, lin2;
+    float *norm_w[4] = {}, *norm_b[4] = {};   // norm1, norm2, norm3 (cross only), norm_out
+    float *gamma1 = nullptr, *gamma2 = nullptr;
+};
+
+struct Model {
+    mi_config cfg{};
+    int S = 0, SL = 0, T = 0, Lt[5] = {};
+    int64_t device_bytes = 0;
+    std::vector<void *> allocs;
+
+    FftTables fft{};
+    EncW enc[4], tenc[4];
+    DecW dec[4], tdec[4];
+    float *freq_emb = nullptr;
+    PackedConv chan[4];
+    mi_ktab_entry *chan_ktab[4] = {};
+    mi_ktab_entry *tr_ktab512[2] = {}, *tr_ktab2048[2] = {};
+    float *norm_in_w[2] = {}, *norm_in_b[2] = {}, *pos_emb[2] = {};
+    TrLayerW tr[2][5];
+
+    // workspace (sized for cfg.max_batch)
+    float *w_xt0 = nullptr, *w_zt = nullptr, *w_x0 = nullptr;
+    float *w_skip[4] = {}, *w_skip_t[4] = {};
+    float *w_a = nullptr, *w_b = nullptr, *w_c = nullptr, *w_h = nullptr;
+    float *w_ta = nullptr, *w_tb = nullptr, *w_tc = nullptr, *w_th = nullptr;
+    float *w_tr_x[2][2] = {}, *w_tr_ln[2] = {}, *w_tr_ln2[2] = {}, *w_tr_qkv[2] = {}, *w_tr_att[2] = {}, *w_tr_x1[2] = {},
+          *w_tr_x2[2] = {}, *w_tr_ffh[2] = {};
+    float *w_yspec = nullptr, *w_ytime = nullptr, *w_yt = nullptr, *w_fr = nullptr;
+    double *w_stats = nullptr, *w_stats_t = nullptr;
+    float2 *w_st1 = nullptr, *w_st2 = nullptr, *w_st1_t = nullptr, *w_st2_t = nullptr;
+    float2 *w_norm_f = nullptr, *w_denorm_f = nullptr, *w_norm_t = nullptr, *w_denorm_t = nullptr;
+
+    ~Model();
+    int init(const mi_config &c, const mi_tensor_desc *weights, size_t n);
+    int forward(const float *mix, float *out, int B, hipStream_t st);
+
+   private:
+    int dev_alloc(void **p, size_t bytes);
+    template <typename T> int upload(const std::vector<T> &h, T **dptr);
+    int pack_conv(const float *W, const float *bias, int M, int K, bool glu, PackedConv *pc);
+    int pack_convtr(const float *W, const float *bias, int Cin, int Cout, PackedConv *pc);
+    int pack_vec(const float *v, int n, int npad, bool glu, float **out);
+    int make_ktab(const Gather &g, int Kpad, mi_ktab_entry **out);
+    int load_dconv(const WeightTable &wt, const std::string &prefix, int C, int64_t chan_stride, int D2, DConvW *dw);
+    int alloc_workspace();
+    int run_dconv(const DConvW &w, int C, const Geo &g, float *x, float *tmp, float *hidden, double *stats, float2 *st1, float2 *st2,
+                  hipStream_t st);
+    int run_tr_layer(int br, int k, int B, const float *x, const float *other, float *out, hipStream_t st);
+};
+
+}  // namespace mi

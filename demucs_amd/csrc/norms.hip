@@ -1,0 +1,165 @@
+// Normalisation kernels (HBM-bound, wave64 reductions): per-item input normalisation
+// (reference: demucs/htdemucs.py:545-554), LayerNorm over channels of channel-first tokens,
+// GroupNorm(1) over (tokens, channels) (demucs/transformer.py:258-268), statistics finalisation.
+#include "common.h"
+#include "kernels.h"
+
+namespace mi {
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+// block-wide (256 threads) sum of two doubles -> thread 0
+__device__ __forceinline__ void block_sum2(double &a, double &b, double *red /*[8]*/) {
+    a = wave_sum(a); b = wave_sum(b);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[2 * w] = a; red[2 * w + 1] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) { a = red[0] + red[2] + red[4] + red[6]; b = red[1] + red[3] + red[5] + red[7]; }
+}
+
+// sum / sum-of-squares of `count` contiguous floats per row -> stats[row][slot][2] (fp64 atomics).
+// grid (nblk, rows)
+__global__ __launch_bounds__(256) void row_stats_kernel(const float *__restrict__ x, int64_t count, int64_t row_stride,
+                                                        double *__restrict__ stats) {
+    __shared__ double red[8];
+    const float *p = x + (size_t)blockIdx.y * row_stride;
+    const int64_t per = (count + gridDim.x - 1) / gridDim.x;
+    const int64_t lo = (int64_t)blockIdx.x * per, hi = min(count, lo + per);
+    double s1 = 0.0, s2 = 0.0;
+    for (int64_t base = lo; base < hi; base += 256 * 16) {      // fp32 partials over <=16 elements, fp64 across
+        float a = 0.f, q = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int64_t i = base + threadIdx.x + 256 * j;
+            if (i < hi) { const float v = p[i]; a += v; q += v * v; }
+        }
+        s1 += a; s2 += q;
+    }
+    block_sum2(s1, s2, red);
+    if (threadIdx.x == 0) {
+        double *dst = stats + ((size_t)blockIdx.y * kStatSlots + (blockIdx.x % kStatSlots)) * 2;
+        atomicAdd(dst, s1); atomicAdd(dst + 1, s2);
+    }
+}
+
+// mode 0: GroupNorm   -> out_a[row] = (mean, 1/sqrt(var_biased + eps))
+// mode 1: item norm   -> out_a[row] = (mean, 1/(eps + std_unbiased)), out_b[row] = (mean, std_unbiased)
+__global__ void finalize_stats_kernel(const double *__restrict__ stats, int rows, double count, float eps, int mode,
+                                      float2 *__restrict__ out_a, float2 *__restrict__ out_b) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= rows) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int s = 0; s < kStatSlots; ++s) {
+        s1 += stats[((size_t)row * kStatSlots + s) * 2];
+        s2 += stats[((size_t)row * kStatSlots + s) * 2 + 1];
+    }
+    const double mean = s1 / count;
+    double m2 = s2 - s1 * mean;          // sum (x - mean)^2
+    if (m2 < 0.0) m2 = 0.0;
+    if (mode == 0) {
+        const float var = (float)(m2 / count);
+        out_a[row] = make_float2((float)mean, 1.0f / sqrtf(var + eps));
+    } else {
+        const float sd = (float)sqrt(m2 / (count - 1.0));
+        out_a[row] = make_float2((float)mean, 1.0f / (eps + sd));
+        if (out_b) out_b[row] = make_float2((float)mean, sd);
+    }
+}
+
+// y[row][i] = (x[row][i] - mean[row]) * inv[row]
+__global__ __launch_bounds__(256) void row_affine_kernel(const float *__restrict__ x, int64_t count, const float2 *__restrict__ norm,
+                                                         float *__restrict__ y) {
+    const float2 nm = norm[blockIdx.y];
+    const size_t base = (size_t)blockIdx.y * count;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256)
+        y[base + i] = (x[base + i] - nm.x) * nm.y;
+}
+
+// LayerNorm over C channels of channel-first tokens x[b][C][T]; optional additive table pe[C][T].
+// grid (ceil(T/64), B), block 256: lane = token, wave w owns channels [w*C/4, (w+1)*C/4).
+__global__ __launch_bounds__(256) void layernorm_cf_kernel(const float *__restrict__ x, int C, int T, const float *__restrict__ w,
+                                                           const float *__restrict__ bvec, const float *__restrict__ pe, float eps,
+                                                           float *__restrict__ y) {
+    __shared__ float red[4][64][2];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int t = blockIdx.x * 64 + lane;
+    const bool ok = t < T;
+    const size_t base = (size_t)blockIdx.y * C * T + (ok ? t : 0);
+    const int cw = C / 4, c0 = wv * cw;
+    const float x0 = x[base];                         // shift: removes cancellation in sum of squares
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = c0; c < c0 + cw; ++c) {
+        const float v = x[base + (size_t)c * T] - x0;
+        s1 += v; s2 += v * v;
+    }
+    red[wv][lane][0] = s1; red[wv][lane][1] = s2;
+    __syncthreads();
+    s1 = red[0][lane][0] + red[1][lane][0] + red[2][lane][0] + red[3][lane][0];
+    s2 = red[0][lane][1] + red[1][lane][1] + red[2][lane][1] + red[3][lane][1];
+    const float inv_c = 1.0f / (float)C;
+    const float dm = s1 * inv_c;
+    const float mean = x0 + dm;
+    const float var = fmaxf(s2 * inv_c - dm * dm, 0.f);
+    const float rstd = 1.0f / sqrtf(var + eps);
+    if (!ok) return;
+    for (int c = c0; c < c0 + cw; ++c) {
+        float v = (x[base + (size_t)c * T] - mean) * rstd * w[c] + bvec[c];
+        if (pe) v += pe[(size_t)c * T + t];
+        y[base + (size_t)c * T] = v;
+    }
+}
+
+// y[b][c][t] = (x - mean[b]) * rstd[b] * w[c] + bias[c]   (GroupNorm(1, C) apply), grid (ceil(T/256), C, B)
+__global__ __launch_bounds__(256) void gn_apply_cf_kernel(const float *__restrict__ x, int C, int T, const float2 *__restrict__ st,
+                                                          const float *__restrict__ w, const float *__restrict__ bvec,
+                                                          float *__restrict__ y) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= T) return;
+    const int c = blockIdx.y, b = blockIdx.z;
+    const float2 s = st[b];
+    const size_t i = ((size_t)b * C + c) * T + t;
+    y[i] = (x[i] - s.x) * s.y * w[c] + bvec[c];
+}
+
+int launch_row_stats(const float *x, int rows, int64_t count, int64_t row_stride, double *stats, hipStream_t st) {
+    MI_HIP(hipMemsetAsync(stats, 0, sizeof(double) * 2 * kStatSlots * rows, st));
+    const int nblk = (int)std::min<int64_t>(256, (count + 4095) / 4096);
+    hipLaunchKernelGGL(row_stats_kernel, dim3(nblk, rows), dim3(256), 0, st, x, count, row_stride, stats);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+
+int launch_finalize_stats(const double *stats, int rows, double count, float eps, int mode, float2 *out_a, float2 *out_b,
+                          hipStream_t st) {
+    hipLaunchKernelGGL(finalize_stats_kernel, dim3(ceil_div(rows, 64)), dim3(64), 0, st, stats, rows, count, eps, mode, out_a, out_b);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+
+int launch_row_affine(const float *x, int rows, int64_t count, const float2 *norm, float *y, hipStream_t st) {
+    const int nblk = (int)std::min<int64_t>(1024, (count + 255) / 256);
+    hipLaunchKernelGGL(row_affine_kernel, dim3(nblk, rows), dim3(256), 0, st, x, count, norm, y);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+
+int launch_layernorm_cf(const float *x, int B, int C, int T, const float *w, const float *b, const float *pe, float *y,
+                        hipStream_t st) {
+    MI_REQUIRE(C % 4 == 0, "layernorm: C %% 4 != 0");
+    hipLaunchKernelGGL(layernorm_cf_kernel, dim3(ceil_div(T, 64), B), dim3(256), 0, st, x, C, T, w, b, pe, 1e-5f, y);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+
+int launch_gn_apply_cf(const float *x, int B, int C, int T, const float2 *stats, const float *w, const float *b, float *y,
+                       hipStream_t st) {
+    hipLaunchKernelGGL(gn_apply_cf_kernel, dim3(ceil_div(T, 256), C, B), dim3(256), 0, st, x, C, T, stats, w, b, y);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+
+}  // namespace mi

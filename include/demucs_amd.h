@@ -1,0 +1,135 @@
+/* demucs_amd.h — C ABI of the MI355X (gfx950) HTDemucs segment-inference engine.
+ *
+ * The upstream project (DrorT/demucs) is pure Python and has no FFI; its boundary for this
+ * path is a Python call + a weight schema.  Each entry point below names the reference
+ * interface it stands in for (paths relative to the reference checkout).  A maintainer binds
+ * them with ctypes (demucs_amd/_lib.py is that binding).
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative MI_E* code; nothing throws across the
+ *     ABI; `mi_last_error()` returns a thread-local, NUL-terminated description of the last
+ *     failure on the calling thread.
+ *   - `*_dev` pointers are device (HBM) addresses owned by the caller (e.g. torch tensors'
+ *     data_ptr()), contiguous float32 unless stated; `stream` is a hipStream_t (NULL = the
+ *     default stream).  All work is enqueued asynchronously on `stream`; no call synchronises
+ *     the device except mi_model_create / mi_model_destroy.
+ *   - a handle is single-stream: do not use one handle from two streams/threads at once;
+ *     different handles are independent.
+ */
+#ifndef DEMUCS_AMD_H
+#define DEMUCS_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI_OK 0
+#define MI_EINVAL (-1)   /* bad argument / unsupported configuration            */
+#define MI_EHIP (-2)     /* a HIP runtime call failed (see mi_last_error)        */
+#define MI_ENOMEM (-3)   /* device or host allocation failed                     */
+#define MI_EWEIGHT (-4)  /* missing / mis-shaped tensor in the weight table      */
+
+/* One tensor of a reference `state_dict()` (demucs/states.py:83-107 yields these names;
+ * schema in SURVEY.md App. B).  `data` is a HOST pointer to float32, row-major, `numel`
+ * elements; the library copies what it needs before mi_model_create returns. */
+typedef struct mi_tensor_desc {
+    const char *name;
+    const float *data;
+    int64_t numel;
+} mi_tensor_desc;
+
+/* Architecture = the released htdemucs family (demucs/htdemucs.py:56-133 with
+ * channels=48, depth=4, nfft=4096, dconv_mode=3, bottom_channels=512, t_layers=5, t_heads=8). */
+typedef struct mi_config {
+    int32_t n_sources;       /* len(model.sources): 4 (htdemucs, htdemucs_ft) or 6 (htdemucs_6s) */
+    int32_t segment_length;  /* int(model.segment * model.samplerate) = 343980                   */
+    int32_t max_batch;       /* segments per forward the workspace is sized for                  */
+    int32_t reserved;
+} mi_config;
+
+/* ---- model lifetime: replaces `states.load_model` + `model.to(device)`
+ *      (demucs/states.py:50-80, demucs/apply.py:233) ------------------------------------- */
+int mi_model_create(const mi_config *cfg, const mi_tensor_desc *weights, size_t n_weights, void **handle);
+void mi_model_destroy(void *handle);
+
+/* ---- `model(padded_mix)` under no_grad (demucs/apply.py:316-317 -> HTDemucs.forward,
+ *      demucs/htdemucs.py:527-660).  mix_dev: (B, 2, segment_length); out_dev:
+ *      (B, n_sources, 2, segment_length).  1 <= B <= max_batch. ---------------------------- */
+int mi_model_forward(void *handle, const float *mix_dev, float *out_dev, int32_t B, void *stream);
+
+/* Debug / parity aid: copy an internal activation left behind by the last mi_model_forward
+ * (first B items) into dst_dev (may be NULL to query *numel_per_item only).  Names: "x0" (normalised CaC spectrogram),
+ * "xt0", "enc0".."enc3", "tenc0".."tenc3" (encoder outputs = skip tensors), "tr_f", "tr_t"
+ * (transformer outputs, channel-first), "yspec", "ytime" (decoder outputs before iSTFT). */
+int mi_model_tap(void *handle, const char *name, float *dst_dev, int32_t B, int64_t *numel_per_item, void *stream);
+
+/* Device bytes held by the handle (weights + workspace). */
+int64_t mi_model_device_bytes(void *handle);
+
+/* ---- segment scheduler pieces (demucs/apply.py:257-301,108-124) --------------------------
+ * Index arrays (`*_idx_dev`) are DEVICE arrays (tiny; e.g. torch int tensors) so that every call
+ * stays asynchronous on `stream`.
+ *
+ * mi_segments_gather: TensorChunk.padded for a batch of segments.  For item i the segment is
+ *   the `valid`-long window starting at track sample starts[i] (may be negative / run past the
+ *   end: zero filled) of track_dev (channels, track_len); seg_dev is (B, channels, valid). */
+int mi_segments_gather(const float *track_dev, int64_t track_len, int32_t channels, const int64_t *starts_idx_dev,
+                       int32_t B, int32_t valid, float *seg_dev, void *stream);
+
+/* mi_ola_accumulate: `out[..., off:off+SL] += weight[:n] * chunk_out` for a batch
+ *   (demucs/apply.py:295-296) with chunk_out = center_trim(model_out, n) (utils.py:38-54).
+ *   model_out_dev: (B, rows, valid), rows = n_sources*channels; item i contributes samples
+ *   [trim[i], trim[i]+lens[i]) of its rows, weighted by weight_dev[0:lens[i]], to
+ *   acc_dev (rows, acc_len) at acc position offs[i].  [span_lo, span_hi) is the union of the
+ *   items' acc ranges.  Items are applied in index order with separately rounded float32
+ *   product and sum, i.e. exactly the reference's sequential loop. */
+int mi_ola_accumulate(float *acc_dev, int64_t acc_len, int32_t rows, const float *model_out_dev, int32_t valid,
+                      const int64_t *offs_idx_dev, const int32_t *lens_idx_dev, const int32_t *trim_idx_dev, int32_t B,
+                      int64_t span_lo, int64_t span_hi, const float *weight_dev, void *stream);
+
+/* mi_ola_finish: `out /= sum_weight` (demucs/apply.py:297-299); sum_weight is rebuilt from the
+ *   (offs, lens) list of ALL segments of the track (sorted by offset, track coordinates) in the
+ *   reference's float32 summation order.  In place on acc_dev (rows, acc_len); acc_off0 is the
+ *   track position of acc sample 0; max_len = the segment length. */
+int mi_ola_finish(float *acc_dev, int64_t acc_len, int32_t rows, int64_t acc_off0, const int64_t *offs_idx_dev,
+                  const int32_t *lens_idx_dev, int32_t n_segments, int32_t max_len, const float *weight_dev, void *stream);
+
+/* ---- kernel-level entry points (parity tests; same kernels the forward uses) --------------
+ * mi_stft_cac: `_magnitude(_spec(mix))` (demucs/htdemucs.py:420-461, demucs/spec.py:11-27):
+ *   mix_dev (B,2,L) -> cac_dev (B,4,2048,ceil(L/1024)), channel order [c0.re,c0.im,c1.re,c1.im]. */
+int mi_stft_cac(const float *mix_dev, int32_t B, int32_t L, float *cac_dev, void *stream);
+/* mi_istft_cac: `_ispec(_mask(z, x), length)` (demucs/htdemucs.py:442-471, demucs/spec.py:30-47):
+ *   x_dev (B,S,4,2048,T) -> wav_dev (B,S,2,L) with T = ceil(L/1024). */
+int mi_istft_cac(const float *x_dev, int32_t B, int32_t S, int32_t L, float *wav_dev, void *stream);
+
+/* Generic convolution / linear layer evaluated by the implicit-GEMM MFMA kernel (stands in for
+ *   F.conv1d / F.conv2d / F.conv_transpose / F.linear as invoked at demucs/hdemucs.py:110,116,
+ *   136,153,287,294,313,326, demucs/demucs.py:138,140, demucs/htdemucs.py:589-599).
+ *   See demucs_amd/csrc/gemm_conv.h (mi_conv_desc) for the field meanings. */
+struct mi_conv_desc;
+int mi_conv_forward(const struct mi_conv_desc *desc, void *stream);
+
+/* Multi-head attention core softmax(QK^T/sqrt(64))V on channel-first tensors (stands in for the
+ *   attention inside nn.MultiheadAttention, called at demucs/transformer.py:418-419,506):
+ *   q_dev (B, heads*64, Tq) with row stride q_ld..., see demucs_amd/csrc/attention.h. */
+int mi_attention(const float *q_dev, const float *k_dev, const float *v_dev, float *o_dev, int32_t B, int32_t heads,
+                 int32_t Tq, int32_t Tk, int64_t q_batch_stride, int64_t kv_batch_stride, int64_t o_batch_stride,
+                 void *stream);
+
+/* LayerNorm over the channel axis of channel-first tokens x (B, C, T), optional additive table
+ *   add_dev (C, T) (nn.LayerNorm at demucs/transformer.py:434-436,591-592 + positional
+ *   embedding add :655-663). */
+int mi_layernorm_cf(const float *x_dev, int32_t B, int32_t C, int32_t T, const float *w_dev, const float *b_dev,
+                    const float *add_dev, float *y_dev, void *stream);
+
+const char *mi_last_error(void);
+/* "demucs_amd <version> gfx950" */
+const char *mi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEMUCS_AMD_H */

@@ -1,0 +1,269 @@
+"""Kernel-level parity on a real MI355X, through the C ABI, against float64 CPU math
+(the oracle's definitions for STFT/iSTFT; torch CPU float64 conv / attention for the GEMM paths).
+
+Tolerances (float32 kernels vs float64 truth, inputs O(1)): stated per test; they are a few
+units of float32 rounding times sqrt(K) of the contraction length.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from demucs_amd import _lib
+from demucs_amd.synth import synth_mix
+from oracle import htdemucs_oracle as O
+
+pytestmark = pytest.mark.gpu
+SL = 343980
+
+
+@pytest.fixture(scope="module")
+def lib():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return _lib.load()
+
+
+def stream():
+    return C.c_void_p(_lib.current_stream_ptr())
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g, dtype=torch.float64) * scale
+
+
+# ------------------------------------------------------------------------------------------------
+def test_stft_matches_oracle(lib):
+    mix = torch.stack([torch.from_numpy(synth_mix(3, SL, "tones")), torch.from_numpy(synth_mix(4, SL, "noise"))])
+    want = O.stft_cac(mix.double())
+    out = torch.empty(2, 4, 2048, 336, device="cuda")
+    mixd = mix.cuda()
+    _lib.check(lib.mi_stft_cac(mixd.data_ptr(), 2, SL, out.data_ptr(), stream()), "mi_stft_cac")
+    err = (out.cpu().double() - want).abs().max().item()
+    assert err < 3e-6 * max(1.0, want.abs().max().item()), err     # 4096-point float32 FFT
+
+
+def test_istft_matches_oracle_and_roundtrip(lib):
+    x = rnd(1, 4, 4, 2048, 336, seed=1)
+    want = O.istft_from_cac(x, SL)
+    out = torch.empty(1, 4, 2, SL, device="cuda")
+    xd = x.float().cuda()
+    _lib.check(lib.mi_istft_cac(xd.data_ptr(), 1, 4, SL, out.data_ptr(), stream()), "mi_istft_cac")
+    err = (out.cpu().double() - want).abs().max().item()
+    assert err < 2e-5 * want.abs().max().item(), err
+    # size-independent property: iSTFT(STFT(x)) == x on the interior (samples covered by four kept
+    # frames), up to the Nyquist bin that `_spec` drops (htdemucs.py:437); tight against the oracle's
+    # own round trip everywhere.
+    mix = torch.from_numpy(synth_mix(9, SL, "tones"))[None]
+    spec = torch.empty(1, 4, 2048, 336, device="cuda")
+    mixd = mix.cuda()
+    _lib.check(lib.mi_stft_cac(mixd.data_ptr(), 1, SL, spec.data_ptr(), stream()), "mi_stft_cac")
+    back = torch.empty(1, 1, 2, SL, device="cuda")
+    _lib.check(lib.mi_istft_cac(spec.data_ptr(), 1, 1, SL, back.data_ptr(), stream()), "mi_istft_cac")
+    back = back.cpu()[0, 0]
+    rt = (back - mix[0])[:, 1536:342528].abs().max().item()
+    assert rt < 2e-3, rt
+    oracle_rt = O.istft_from_cac(O.stft_cac(mix.double())[:, None], SL)[0, 0]
+    assert (back.double() - oracle_rt).abs().max().item() < 5e-6
+
+
+# ------------------------------------------------------------------------------------------------
+from gpu_helpers import (EPI_BIAS_STATS, EPI_CONVTR, EPI_GLU, EPI_GN_GLU, EPI_LINEAR, EPI_STATS_ONLY, FLAG_EMB,  # noqa: E402
+                         FLAG_GELU, FLAG_RES, FLAG_SCALE, FLAG_TR_FREQ, SLOTS, conv_call, ktab, maxerr, pack_vec, pack_w)
+
+
+def test_conv_freq_strided_gelu(lib):
+    """HEncLayer conv on the frequency axis: Conv2d k=(8,1) s=(4,1) p=(2,0) + GELU (hdemucs.py:110,136,144)."""
+    B, Cin, Cout, Fr, T = 2, 12, 96, 64, 48
+    x, W, b = rnd(B, Cin, Fr, T, seed=2), rnd(Cout, Cin, 8, 1, seed=3, scale=0.1), rnd(Cout, seed=4)
+    want = F.gelu(F.conv2d(x, W, b, stride=(4, 1), padding=(2, 0)))
+    wt, bias, M, Mpad, K, Kpad, tile = pack_w(W.reshape(Cout, -1), b)
+    kt = ktab(Cin, 8, 1, 1, 1, 2, 0, Fr * T, T, Kpad)
+    y = torch.empty(B, Cout, Fr // 4, T, device="cuda")
+    P = Fr // 4 * T
+    conv_call(wt=wt, M=M, Mpad=Mpad, K=K, Kpad=Kpad, ktab=kt, x=x.float().cuda(), x_bstride=Cin * Fr * T, B=B, D1=Fr, D2=T,
+              O1=Fr // 4, O2=T, S1=4, S2=1, row_mode=1, epi=EPI_LINEAR, flags=FLAG_GELU, bias=bias, y=y, y_bstride=Cout * P,
+              y_cstride=P, tile_m=tile)
+    assert maxerr(y, want) < 2e-5
+
+
+def test_conv_time_strided_ragged(lib):
+    """HEncLayer conv on the time axis with a length that is not a multiple of the stride
+    (right zero padding, hdemucs.py:132-136): L=5375 -> 1344."""
+    B, Cin, Cout, L = 2, 6, 48, 5375
+    x, W, b = rnd(B, Cin, L, seed=5), rnd(Cout, Cin, 8, seed=6, scale=0.2), rnd(Cout, seed=7)
+    want = F.conv1d(F.pad(x, (0, 1)), W, b, stride=4, padding=2)
+    Lo = want.shape[-1]
+    wt, bias, M, Mpad, K, Kpad, tile = pack_w(W.reshape(Cout, -1), b)
+    kt = ktab(Cin, 1, 8, 1, 1, 0, 2, L, L, Kpad)
+    y = torch.empty(B, Cout, Lo, device="cuda")
+    conv_call(wt=wt, M=M, Mpad=Mpad, K=K, Kpad=Kpad, ktab=kt, x=x.float().cuda(), x_bstride=Cin * L, B=B, D1=1, D2=L, O1=1, O2=Lo,
+              S1=1, S2=4, epi=EPI_LINEAR, bias=bias, y=y, y_bstride=Cout * Lo, y_cstride=Lo, tile_m=tile)
+    assert maxerr(y, want) < 2e-5
+
+
+def test_conv_3x3_glu_and_emb(lib):
+    """HDecLayer rewrite Conv2d 3x3 + GLU (hdemucs.py:294,313), plus the additive per-(c, fr) table."""
+    B, C, Fr, T = 1, 24, 16, 80
+    x, W, b = rnd(B, C, Fr, T, seed=8), rnd(2 * C, C, 3, 3, seed=9, scale=0.1), rnd(2 * C, seed=10)
+    emb = rnd(C, Fr, seed=11)
+    want = F.glu(F.conv2d(x, W, b, padding=1), dim=1) + emb[None, :, :, None]
+    wt, bias, M, Mpad, K, Kpad, tile = pack_w(W.reshape(2 * C, -1), b, glu=True)
+    kt = ktab(C, 3, 3, 1, 1, 1, 1, Fr * T, T, Kpad)
+    y = torch.empty(B, C, Fr, T, device="cuda")
+    P = Fr * T
+    conv_call(wt=wt, M=M, Mpad=Mpad, K=K, Kpad=Kpad, ktab=kt, x=x.float().cuda(), x_bstride=C * P, B=B, D1=Fr, D2=T, O1=Fr, O2=T,
+              S1=1, S2=1, row_mode=1, epi=EPI_GLU, flags=FLAG_EMB, emb=emb.float().cuda().contiguous(), bias=bias, y=y,
+              y_bstride=C * P, y_cstride=P, tile_m=tile)
+    assert maxerr(y, want) < 2e-5
+
+
+def test_linear_scale_residual_big_k(lib):
+    """nn.Linear on channel-first tokens with LayerScale + residual epilogue (transformer.py:364-367):
+    M=512, K=2048 exercises the 128-row tile and a long contraction."""
+    B, M, K, Tn = 2, 512, 2048, 300
+    x, W, b = rnd(B, K, Tn, seed=12), rnd(M, K, seed=13, scale=0.03), rnd(M, seed=14)
+    g, r = rnd(M, seed=15), rnd(B, M, Tn, seed=16)
+    want = r + g[None, :, None] * (torch.einsum("mk,bkt->bmt", W, x) + b[None, :, None])
+    wt, bias, M_, Mpad, K_, Kpad, tile = pack_w(W, b)
+    kt = ktab(K, 1, 1, 1, 1, 0, 0, Tn, Tn, Kpad)
+    y = torch.empty(B, M, Tn, device="cuda")
+    conv_call(wt=wt, M=M, Mpad=Mpad, K=K, Kpad=Kpad, ktab=kt, x=x.float().cuda(), x_bstride=K * Tn, B=B, D1=1, D2=Tn, O1=1, O2=Tn,
+              S1=1, S2=1, epi=EPI_LINEAR, flags=FLAG_SCALE | FLAG_RES, scale=pack_vec(g, Mpad), res=r.float().cuda(), bias=bias,
+              y=y, y_bstride=M * Tn, y_cstride=Tn, tile_m=tile)
+    assert maxerr(y, want) < 6e-5
+
+
+@pytest.mark.parametrize("freq", [True, False])
+def test_conv_transpose_4phase(lib, freq):
+    """ConvTranspose k=8 s=4 + crop + GELU + skip add (hdemucs.py:287,326-334) as a 4-phase GEMM."""
+    if freq:
+        B, C, Co, Fr, T = 2, 24, 12, 8, 40
+        x, W, b = rnd(B, C, Fr, T, seed=17), rnd(C, Co, 8, 1, seed=18, scale=0.2), rnd(Co, seed=19)
+        skip = rnd(B, Co, 4 * Fr, T, seed=20)
+        want = F.gelu(F.conv_transpose2d(x, W, b, stride=(4, 1))[..., 2:-2, :]) + skip
+    else:
+        B, C, Co, L, Lout = 2, 24, 12, 345, 1377        # ragged: the reference crops [2 : 2 + length]
+        x, W, b = rnd(B, C, L, seed=21), rnd(C, Co, 8, seed=22, scale=0.2), rnd(Co, seed=23)
+        skip = rnd(B, Co, Lout, seed=24)
+        want = F.gelu(F.conv_transpose1d(x, W, b, stride=4)[..., 2:2 + Lout]) + skip
+    Wr = W.reshape(C, Co, 8)
+    W2 = torch.zeros(4 * Co, 2 * C, dtype=torch.float64)       # row 4co+r, col 2ci+j  <- W[ci][co][r+4j]
+    for r in range(4):
+        for j in range(2):
+            W2[r::4, j::2] = Wr[:, :, r + 4 * j].t()
+    wt, bias, M, Mpad, K, Kpad, tile = pack_w(W2, b.repeat_interleave(4))
+    if freq:
+        kt = ktab(C, 2, 1, -1, 1, 0, 0, Fr * T, T, Kpad)
+        y = torch.empty(B, Co, 4 * Fr, T, device="cuda")
+        conv_call(wt=wt, M=M, Mpad=Mpad, K=K, Kpad=Kpad, ktab=kt, x=x.float().cuda(), x_bstride=C * Fr * T, B=B, D1=Fr, D2=T,
+                  O1=Fr + 1, O2=T, S1=1, S2=1, row_mode=1, epi=EPI_CONVTR, flags=FLAG_TR_FREQ | FLAG_GELU | FLAG_RES,
+                  res=skip.float().cuda(), bias=bias, y=y, y_bstride=Co * 4 * Fr * T, y_cstride=4 * Fr * T, out_len=4 * Fr,
+                  tile_m=tile)
+    else:
+        kt = ktab(C, 1, 2, 1, -1, 0, 0, L, L, Kpad)
+        y = torch.empty(B, Co, Lout, device="cuda")
+        conv_call(wt=wt, M=M, Mpad=Mpad, K=K, Kpad=Kpad, ktab=kt, x=x.float().cuda(), x_bstride=C * L, B=B, D1=1, D2=L, O1=1,
+                  O2=L + 1, S1=1, S2=1, epi=EPI_CONVTR, flags=FLAG_GELU | FLAG_RES, res=skip.float().cuda(), bias=bias, y=y,
+                  y_bstride=Co * Lout, y_cstride=Lout, out_len=Lout, tile_m=tile)
+    assert maxerr(y, want) < 2e-5
+
+
+@pytest.mark.parametrize("freq", [True, False])
+def test_dconv_layer_three_passes(lib, freq):
+    """One DConv residual layer (demucs.py:138-143,151-154): dilated conv3 + per-row statistics,
+    GroupNorm(1)+GELU prologue, 1x1 with statistics-only pass, then GroupNorm + GLU + LayerScale +
+    residual epilogue.  Frequency branch rows are (b, fr); time branch rows are b."""
+    C, h, dil = 48, 6, 2
+    if freq:
+        B, Fr, T = 2, 5, 336
+        x4 = rnd(B, C, Fr, T, seed=25)
+        rows_x = x4.permute(0, 2, 1, 3).reshape(B * Fr, C, T)
+        D1, D2, row_mode, nrows = Fr, T, 1, B * Fr
+    else:
+        B, L = 2, 2000
+        x4 = rnd(B, C, L, seed=25)
+        rows_x = x4
+        D1, D2, row_mode, nrows = 1, L, 0, B
+    W0, b0 = rnd(h, C, 3, seed=26, scale=0.2), rnd(h, seed=27)
+    g1w, g1b = 1 + 0.2 * rnd(h, seed=28), 0.1 * rnd(h, seed=29)
+    W3, b3 = rnd(2 * C, h, 1, seed=30, scale=0.5), rnd(2 * C, seed=31)
+    g2w, g2b = 1 + 0.2 * rnd(2 * C, seed=32), 0.1 * rnd(2 * C, seed=33)
+    ls = 1 + 0.3 * rnd(C, seed=34)
+    y = F.conv1d(rows_x, W0, b0, dilation=dil, padding=dil)
+    y = F.gelu(F.group_norm(y, 1, g1w, g1b, eps=1e-5))
+    y = F.group_norm(F.conv1d(y, W3, b3), 1, g2w, g2b, eps=1e-5)
+    want_rows = rows_x + ls[:, None] * F.glu(y, dim=1)
+    want = want_rows.view(B, Fr, C, T).permute(0, 2, 1, 3) if freq else want_rows
+
+    P = D1 * D2
+    xd = x4.float().cuda().contiguous()
+    # pass 1: conv3 + bias, per-row statistics
+    wt0, bias0, M0, Mpad0, K0, Kpad0, tile0 = pack_w(W0.reshape(h, -1), b0)
+    kt0 = ktab(C, 1, 3, 1, dil, 0, dil, P, D2, Kpad0)
+    hid = torch.empty(B, h, P, device="cuda")
+    stats = torch.zeros(nrows, SLOTS, 2, dtype=torch.float64, device="cuda")
+    conv_call(wt=wt0, M=M0, Mpad=Mpad0, K=K0, Kpad=Kpad0, ktab=kt0, x=xd, x_bstride=C * P, B=B, D1=D1, D2=D2, O1=D1, O2=D2, S1=1,
+              S2=1, row_mode=row_mode, epi=EPI_BIAS_STATS, bias=bias0, y=hid, y_bstride=h * P, y_cstride=P, stats=stats,
+              tile_m=tile0)
+    s = stats.sum(1).cpu()
+    cnt = h * D2 if freq else h * P
+    mean = s[:, 0] / cnt
+    var = s[:, 1] / cnt - mean ** 2
+    ref_h = F.conv1d(rows_x, W0, b0, dilation=dil, padding=dil)
+    assert (mean - ref_h.mean(dim=(1, 2))).abs().max() < 1e-6
+    assert (var - ref_h.var(dim=(1, 2), unbiased=False)).abs().max() < 1e-5
+    st1 = torch.stack([mean, 1.0 / torch.sqrt(var + 1e-5)], 1).float().cuda().contiguous()
+    # pass 2: statistics of the 1x1 output (nothing stored)
+    wt3, bias3, M3, Mpad3, K3, Kpad3, tile3 = pack_w(W3.reshape(2 * C, h), b3, glu=True)
+    kt3 = ktab(h, 1, 1, 1, 1, 0, 0, P, D2, Kpad3)
+    stats.zero_()
+    common = dict(wt=wt3, M=M3, Mpad=Mpad3, K=K3, Kpad=Kpad3, ktab=kt3, x=hid, x_bstride=h * P, B=B, D1=D1, D2=D2, O1=D1, O2=D2,
+                  S1=1, S2=1, row_mode=row_mode, pro=1, pro_stats=st1, pro_w=g1w.float().cuda(), pro_b=g1b.float().cuda(),
+                  bias=bias3, tile_m=tile3)
+    conv_call(epi=EPI_STATS_ONLY, stats=stats, **common)
+    s = stats.sum(1).cpu()
+    cnt = 2 * C * (D2 if freq else P)
+    mean2 = s[:, 0] / cnt
+    var2 = s[:, 1] / cnt - mean2 ** 2
+    st2 = torch.stack([mean2, 1.0 / torch.sqrt(var2 + 1e-5)], 1).float().cuda().contiguous()
+    # pass 3: recompute, GroupNorm + GLU + LayerScale + residual
+    out = torch.empty_like(xd)
+    conv_call(epi=EPI_GN_GLU, gn_stats=st2, gn_w=pack_vec(g2w, Mpad3, glu=True), gn_b=pack_vec(g2b, Mpad3, glu=True),
+              scale=ls.float().cuda(), res=xd, y=out, y_bstride=C * P, y_cstride=P, **common)
+    assert maxerr(out, want) < 3e-5
+
+
+def test_attention_matches_softmax(lib):
+    """softmax(QK^T/8)V per head on channel-first q/k/v, ragged Tq (not a multiple of 128), cross
+    lengths, and one spiked key forcing a large running-max jump mid-stream."""
+    B, H, Tq, Tk = 2, 8, 200, 320
+    q, k, v = rnd(B, 512, Tq, seed=40), rnd(B, 512, Tk, seed=41), rnd(B, 512, Tk, seed=42)
+    k[:, :, 170] *= 6.0
+    Q = q.view(B, H, 64, Tq).transpose(2, 3)
+    K = k.view(B, H, 64, Tk).transpose(2, 3)
+    V = v.view(B, H, 64, Tk).transpose(2, 3)
+    want = (torch.softmax(Q @ K.transpose(-1, -2) / 8.0, dim=-1) @ V).transpose(2, 3).reshape(B, 512, Tq)
+    kv = torch.cat([k, v], 1).float().cuda().contiguous()          # (B, 1024, Tk) like the packed KV projection
+    o = torch.empty(B, 512, Tq, device="cuda")
+    qd = q.float().cuda()
+    _lib.check(lib.mi_attention(qd.data_ptr(), kv.data_ptr(), kv.data_ptr() + 512 * Tk * 4, o.data_ptr(), B, H, Tq, Tk, 512 * Tq,
+                                1024 * Tk, 512 * Tq, stream()), "mi_attention")
+    torch.cuda.synchronize()
+    assert maxerr(o, want) < 2e-5
+
+
+def test_layernorm_channel_first(lib):
+    B, Cn, Tn = 2, 512, 333
+    x = rnd(B, Cn, Tn, seed=50) * 3 + 40.0          # large mean: checks the shifted one-pass variance
+    w, b, pe = rnd(Cn, seed=51), rnd(Cn, seed=52), rnd(Cn, Tn, seed=53)
+    want = F.layer_norm(x.transpose(1, 2), (Cn,), w, b, eps=1e-5).transpose(1, 2) + pe[None]
+    y = torch.empty(B, Cn, Tn, device="cuda")
+    xd, wd, bd, ped = x.float().cuda(), w.float().cuda(), b.float().cuda(), pe.float().cuda()
+    _lib.check(lib.mi_layernorm_cf(xd.data_ptr(), B, Cn, Tn, wd.data_ptr(), bd.data_ptr(), ped.data_ptr(), y.data_ptr(), stream()),
+               "mi_layernorm_cf")
+    torch.cuda.synchronize()
+    assert maxerr(y, want) < 3e-5
