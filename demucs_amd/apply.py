@@ -1,0 +1,437 @@
+"""Segment scheduler: drop-in for `demucs.apply` (reference: demucs/apply.py:29-322,
+demucs/utils.py:38-54,122-149) with the same names, argument meaning and error behaviour:
+`apply_model`, `BagOfModels`, `TensorChunk`, `tensor_chunk`, plus `center_trim` and
+`DummyPoolExecutor`.
+
+Semantics kept from the reference
+  * bag loop -> shift loop -> overlapping-segment loop -> padded leaf forward + centre trim;
+  * `TensorChunk.padded` fills the padding with the underlying tensor's real neighbours;
+  * triangular `weight ** transition_power` cross-fade, `out /= sum_weight`;
+  * shift offsets come from Python's global `random`, and one `random.randrange(1)` is drawn per
+    segment forward (the reference's transformer does that, transformer.py:680), so seeded runs
+    see the same offsets as the reference;
+  * callback events and their order; exceptions from a segment or a callback propagate;
+  * the result is a new float32 tensor on `mix.device`; `mix` is never mutated.
+
+MI355X-first execution: when the model is `demucs_amd.HTDemucs` on a GPU, the split branch keeps
+the whole track resident in HBM, cuts all segments of a batch with one gather kernel, runs ONE
+batched forward per `model.max_batch` segments, and overlap-adds on the device in the
+reference's summation order (bit-identical to the sequential loop on the same per-segment
+outputs).  Any other model object takes the generic per-segment route (plain torch tensor
+bookkeeping around `model(padded)`), which is also what the CPU host-logic tests exercise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import random
+from concurrent.futures import CancelledError, ThreadPoolExecutor
+from threading import Lock
+from typing import Any, Callable, Dict, List, Optional, Sequence, Union
+
+import torch
+from torch.nn import functional as F
+
+from . import _lib
+from .htdemucs import HTDemucs
+
+__all__ = ["apply_model", "BagOfModels", "TensorChunk", "tensor_chunk", "center_trim", "DummyPoolExecutor"]
+
+
+# ------------------------------------------------------------------------------------------------
+# small pieces with the reference's names
+# ------------------------------------------------------------------------------------------------
+def center_trim(tensor: torch.Tensor, reference: Union[torch.Tensor, int]) -> torch.Tensor:
+    """Trim the last axis to `reference` (a length or a tensor), centred; an odd remainder goes
+    to the right (utils.py:38-54)."""
+    size = reference.size(-1) if isinstance(reference, torch.Tensor) else int(reference)
+    extra = tensor.size(-1) - size
+    if extra < 0:
+        raise ValueError(f"tensor must be larger than reference. Delta is {extra}.")
+    if extra:
+        left = extra // 2
+        tensor = tensor[..., left:left + size]
+    return tensor
+
+
+class DummyPoolExecutor:
+    """Lazy sequential stand-in for an executor: `submit` records the call, `result()` runs it
+    (utils.py:122-149)."""
+
+    class _Deferred:
+        def __init__(self, owner, fn, args, kwargs):
+            self._owner, self._fn, self._args, self._kwargs = owner, fn, args, kwargs
+
+        def result(self):
+            if not self._owner._alive:
+                raise CancelledError()
+            return self._fn(*self._args, **self._kwargs)
+
+    def __init__(self, workers: int = 0):
+        self._alive = True
+
+    def submit(self, fn, *args, **kwargs):
+        return DummyPoolExecutor._Deferred(self, fn, args, kwargs)
+
+    def shutdown(self, *_, **__):
+        self._alive = False
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return None
+
+
+class TensorChunk:
+    """Zero-copy (offset, length) window over the last axis of a tensor (apply.py:82-124)."""
+
+    def __init__(self, tensor, offset: int = 0, length: Optional[int] = None):
+        total = tensor.shape[-1]
+        assert offset >= 0
+        assert offset < total
+        span = total - offset
+        self.length = span if length is None else min(span, length)
+        if isinstance(tensor, TensorChunk):         # windows of windows collapse onto the base tensor
+            self.tensor, self.offset = tensor.tensor, tensor.offset + offset
+        else:
+            self.tensor, self.offset = tensor, offset
+        self.device = tensor.device
+
+    @property
+    def shape(self) -> List[int]:
+        dims = list(self.tensor.shape)
+        dims[-1] = self.length
+        return dims
+
+    def window_start(self, target_length: int) -> int:
+        """Base-tensor index of sample 0 of `padded(target_length)` (may be negative)."""
+        delta = target_length - self.length
+        assert delta >= 0
+        return self.offset - delta // 2
+
+    def padded(self, target_length: int) -> torch.Tensor:
+        begin = self.window_start(target_length)
+        end = begin + target_length
+        total = self.tensor.shape[-1]
+        lo, hi = max(0, begin), min(total, end)
+        out = F.pad(self.tensor[..., lo:hi], (lo - begin, end - hi))
+        assert out.shape[-1] == target_length
+        return out
+
+
+def tensor_chunk(tensor_or_chunk) -> TensorChunk:
+    if isinstance(tensor_or_chunk, TensorChunk):
+        return tensor_or_chunk
+    assert isinstance(tensor_or_chunk, torch.Tensor)
+    return TensorChunk(tensor_or_chunk)
+
+
+class BagOfModels:
+    """Weighted ensemble container (apply.py:29-79).  `weights[i][k]` is the weight of model i for
+    source k.  Call `apply_model` on it; calling it directly raises like the reference."""
+
+    def __init__(self, models: Sequence[Any], weights: Optional[List[List[float]]] = None,
+                 segment: Optional[float] = None):
+        assert len(models) > 0
+        first = models[0]
+        for other in models:
+            assert other.sources == first.sources
+            assert other.samplerate == first.samplerate
+            assert other.audio_channels == first.audio_channels
+            if segment is not None and not isinstance(other, HTDemucs) and segment > other.segment:
+                other.segment = segment
+        self.audio_channels, self.samplerate, self.sources = first.audio_channels, first.samplerate, first.sources
+        self.models = list(models)
+        if weights is None:
+            weights = [[1.0 for _ in first.sources] for _ in models]
+        else:
+            assert len(weights) == len(models)
+            for w in weights:
+                assert len(w) == len(first.sources)
+        self.weights = weights
+
+    @property
+    def max_allowed_segment(self) -> float:
+        limit = float("inf")
+        for m in self.models:
+            if isinstance(m, HTDemucs):
+                limit = min(limit, float(m.segment))
+        return limit
+
+    def forward(self, x):
+        raise NotImplementedError("Call `apply_model` on this.")
+
+    __call__ = forward
+
+
+def _with(d: Optional[dict], **subs) -> dict:
+    out = dict(d) if d is not None else {}
+    out.update(subs)
+    return out
+
+
+def _model_device(model) -> Optional[torch.device]:
+    try:
+        return next(iter(model.parameters())).device
+    except (AttributeError, StopIteration, TypeError):
+        return None
+
+
+def _transition_weight(segment_length: int, transition_power: float, device) -> torch.Tensor:
+    """apply.py:271-276: integer ramps / max (float32), then ** transition_power."""
+    ramp = torch.cat([torch.arange(1, segment_length // 2 + 1, device=device),
+                      torch.arange(segment_length - segment_length // 2, 0, -1, device=device)])
+    assert len(ramp) == segment_length
+    return (ramp / ramp.max()) ** transition_power
+
+
+# ------------------------------------------------------------------------------------------------
+# apply_model
+# ------------------------------------------------------------------------------------------------
+def apply_model(model, mix: Union[torch.Tensor, TensorChunk], shifts: int = 1, split: bool = True,
+                overlap: float = 0.25, transition_power: float = 1.0, progress: bool = False, device=None,
+                num_workers: int = 0, segment: Optional[float] = None, pool=None, lock=None,
+                callback: Optional[Callable[[dict], None]] = None, callback_arg: Optional[dict] = None) -> torch.Tensor:
+    """Apply `model` to `mix` (B, channels, length); see the module docstring and the reference's
+    docstring (apply.py:154-173) for the arguments."""
+    device = mix.device if device is None else torch.device(device)
+    if pool is None:
+        pool = ThreadPoolExecutor(num_workers) if (num_workers > 0 and device.type == "cpu") else DummyPoolExecutor()
+    if lock is None:
+        lock = Lock()
+    callback_arg = _with(callback_arg, model_idx_in_bag=0, shift_idx=0, segment_offset=0)
+    common: Dict[str, Any] = dict(shifts=shifts, split=split, overlap=overlap, transition_power=transition_power,
+                                  progress=progress, device=device, pool=pool, segment=segment, lock=lock)
+
+    if isinstance(model, BagOfModels):
+        return _apply_bag(model, mix, common, callback, callback_arg)
+
+    callback_arg.setdefault("models", 1)
+    model.to(device)
+    model.eval()
+    assert transition_power >= 1, "transition_power < 1 leads to weird behavior."
+    if shifts:
+        return _apply_shifts(model, mix, shifts, common, callback, callback_arg)
+    if split:
+        return _apply_split(model, mix, common, callback, callback_arg)
+    return _apply_leaf(model, mix, common, callback, callback_arg)
+
+
+def _apply_bag(bag: BagOfModels, mix, common, callback, callback_arg) -> torch.Tensor:
+    """apply.py:201-229: each model is applied on its own (its own random shifts), scaled per
+    source, summed, and normalised by the per-source weight totals."""
+    device = common["device"]
+    callback_arg["models"] = len(bag.models)
+    totals = [0.0] * len(bag.sources)
+    estimates = None
+    for sub, sub_weights in zip(bag.models, bag.weights):
+        idx = callback_arg["model_idx_in_bag"]
+        sub_cb = (lambda d, i=idx: callback(_with(d, model_idx_in_bag=i))) if callback else None
+        home = _model_device(sub)
+        sub.to(device)
+        out = apply_model(sub, mix, **common, callback=sub_cb, callback_arg=callback_arg)
+        if home is not None:
+            sub.to(home)
+        for k, w in enumerate(sub_weights):
+            out[:, k, :, :] *= w
+            totals[k] += w
+        estimates = out if estimates is None else estimates.add_(out)
+        del out
+        callback_arg["model_idx_in_bag"] += 1
+    assert isinstance(estimates, torch.Tensor)
+    for k in range(estimates.shape[1]):
+        estimates[:, k, :, :] /= totals[k]
+    return estimates
+
+
+def _apply_shifts(model, mix, shifts: int, common, callback, callback_arg) -> torch.Tensor:
+    """apply.py:237-256: the "shift trick"."""
+    kw = dict(common, shifts=0)
+    length = mix.shape[-1]
+    max_shift = int(0.5 * model.samplerate)
+    padded_mix = tensor_chunk(mix).padded(length + 2 * max_shift)
+    out = None
+    for shift_idx in range(shifts):
+        offset = random.randint(0, max_shift)
+        shifted = TensorChunk(padded_mix, offset, length + max_shift - offset)
+        s_cb = (lambda d, i=shift_idx: callback(_with(d, shift_idx=i))) if callback else None
+        res = apply_model(model, shifted, **kw, callback=s_cb, callback_arg=callback_arg)
+        piece = res[..., max_shift - offset:]
+        out = piece.clone() if out is None else out.add_(piece)
+    out /= shifts
+    return out
+
+
+def _segment_plan(model, length: int, overlap: float, segment):
+    seg = model.segment if segment is None else segment
+    assert seg is not None and seg > 0.0
+    segment_length = int(model.samplerate * seg)
+    stride = int((1 - overlap) * segment_length)
+    return seg, segment_length, stride, list(range(0, length, stride))
+
+
+def _apply_split(model, mix, common, callback, callback_arg) -> torch.Tensor:
+    """apply.py:257-301."""
+    if isinstance(model, HTDemucs) and common["device"].type == "cuda":
+        return _apply_split_device(model, mix, common, callback, callback_arg)
+    kw = dict(common, split=False)
+    device, pool = common["device"], common["pool"]
+    batch, channels, length = mix.shape
+    _, segment_length, stride, offsets = _segment_plan(model, length, common["overlap"], common["segment"])
+    out = torch.zeros(batch, len(model.sources), channels, length, device=mix.device)
+    sum_weight = torch.zeros(length, device=mix.device)
+    weight = _transition_weight(segment_length, common["transition_power"], device)
+    futures = []
+    for offset in offsets:
+        chunk = TensorChunk(mix, offset, segment_length)
+        o_cb = (lambda d, i=offset: callback(_with(d, segment_offset=i))) if callback else None
+        futures.append((pool.submit(apply_model, model, chunk, **kw, callback_arg=callback_arg, callback=o_cb), offset))
+    if common["progress"]:
+        import tqdm
+        scale = float(format(stride / model.samplerate, ".2f"))
+        futures = tqdm.tqdm(futures, unit_scale=scale, ncols=120, unit="seconds")
+    for future, offset in futures:
+        try:
+            chunk_out = future.result()
+        except Exception:
+            pool.shutdown(wait=True, cancel_futures=True)
+            raise
+        n = chunk_out.shape[-1]
+        out[..., offset:offset + segment_length] += (weight[:n] * chunk_out).to(mix.device)
+        sum_weight[offset:offset + segment_length] += weight[:n].to(mix.device)
+    assert sum_weight.min() > 0
+    out /= sum_weight
+    return out
+
+
+def _apply_leaf(model, mix, common, callback, callback_arg) -> torch.Tensor:
+    """apply.py:302-322: pad to the valid length, forward under no_grad, centre-trim."""
+    device, lock, segment = common["device"], common["lock"], common["segment"]
+    length = mix.shape[-1]
+    if isinstance(model, HTDemucs) and segment is not None:
+        valid_length = int(segment * model.samplerate)
+    elif hasattr(model, "valid_length"):
+        valid_length = model.valid_length(length)
+    else:
+        valid_length = length
+    padded_mix = tensor_chunk(mix).padded(valid_length).to(device)
+    with lock:
+        if callback is not None:
+            callback(_with(callback_arg, state="start"))
+    with torch.no_grad():
+        out = model(padded_mix)
+    with lock:
+        if callback is not None:
+            callback(_with(callback_arg, state="end"))
+    assert isinstance(out, torch.Tensor)
+    return center_trim(out, length)
+
+
+# ------------------------------------------------------------------------------------------------
+# device-resident split branch for the HIP engine
+# ------------------------------------------------------------------------------------------------
+def _i64(values, device) -> torch.Tensor:
+    return torch.tensor(list(values), dtype=torch.int64, device=device)
+
+
+def _i32(values, device) -> torch.Tensor:
+    return torch.tensor(list(values), dtype=torch.int32, device=device)
+
+
+def device_split_accumulate(model: HTDemucs, base: torch.Tensor, chunk_offset: int, length: int, offsets: Sequence[int],
+                            segment_length: int, valid_length: int, weight: torch.Tensor, acc: torch.Tensor, acc_origin: int,
+                            on_segment: Optional[Callable[[int], None]] = None) -> None:
+    """Run the segments at `offsets` (relative to the chunk that starts at `chunk_offset` of the
+    device-resident track `base` (channels, total) and is `length` long) and add
+    `weight[:n] * center_trim(model(padded_i), n)` into `acc` (rows, acc_len), whose sample 0 is
+    chunk position `acc_origin`.  One gather + one batched forward + one overlap-add per
+    `model.max_batch` segments.  `on_segment(offset)` is called once per segment, in order."""
+    lib = _lib.load()
+    dev = base.device
+    channels, total = base.shape
+    rows = acc.shape[0]
+    stream = lambda: C.c_void_p(_lib.current_stream_ptr())          # noqa: E731
+    B = model.max_batch
+    SL = model.segment_length          # the engine's fixed forward length; a shorter leaf window is
+    short = valid_length < SL          # right-padded with zeros like HTDemucs.forward does (htdemucs.py:534-537)
+    seg_buf = torch.zeros(B, channels, SL, device=dev, dtype=torch.float32)
+    cut_buf = torch.empty(B, channels, valid_length, device=dev, dtype=torch.float32) if short else seg_buf
+    out_buf = torch.empty(B, len(model.sources), channels, SL, device=dev, dtype=torch.float32)
+    with torch.cuda.device(dev):
+        for i0 in range(0, len(offsets), B):
+            offs = list(offsets[i0:i0 + B])
+            nb = len(offs)
+            lens = [min(length - o, segment_length) for o in offs]
+            trims = [(valid_length - n) // 2 for n in lens]
+            starts = [chunk_offset + o - t for o, t in zip(offs, trims)]            # TensorChunk.padded window
+            # index tensors stay referenced until the launches below are enqueued: the caching allocator
+            # may hand a dropped tensor's block to the next allocation before the kernel has read it
+            t_starts = _i64(starts, dev)
+            _lib.check(lib.mi_segments_gather(base.data_ptr(), total, channels, t_starts.data_ptr(), nb, valid_length,
+                                              cut_buf.data_ptr(), stream()), "mi_segments_gather")
+            if short:
+                seg_buf[:nb, :, :valid_length] = cut_buf[:nb]
+            for o in offs:
+                random.randrange(1)                  # transformer.py:680, once per segment forward
+                if on_segment is not None:
+                    on_segment(o)
+            model.forward_segments(seg_buf[:nb], out_buf[:nb])
+            acc_offs = [o - acc_origin for o in offs]
+            t_offs, t_lens, t_trims = _i64(acc_offs, dev), _i32(lens, dev), _i32(trims, dev)
+            _lib.check(lib.mi_ola_accumulate(acc.data_ptr(), acc.shape[1], rows, out_buf.data_ptr(), SL,
+                                             t_offs.data_ptr(), t_lens.data_ptr(), t_trims.data_ptr(), nb, min(acc_offs),
+                                             max(a + n for a, n in zip(acc_offs, lens)), weight.data_ptr(), stream()),
+                       "mi_ola_accumulate")
+
+
+def device_split_finish(acc: torch.Tensor, acc_origin: int, length: int, offsets: Sequence[int], segment_length: int,
+                        weight: torch.Tensor) -> None:
+    """`out /= sum_weight` on the device, sum_weight rebuilt from ALL segment offsets of the chunk."""
+    lib = _lib.load()
+    dev = acc.device
+    lens = [min(length - o, segment_length) for o in offsets]
+    with torch.cuda.device(dev):
+        t_offs, t_lens = _i64(offsets, dev), _i32(lens, dev)
+        _lib.check(lib.mi_ola_finish(acc.data_ptr(), acc.shape[1], acc.shape[0], acc_origin, t_offs.data_ptr(),
+                                     t_lens.data_ptr(), len(offsets), segment_length, weight.data_ptr(),
+                                     C.c_void_p(_lib.current_stream_ptr())), "mi_ola_finish")
+
+
+def _apply_split_device(model: HTDemucs, mix, common, callback, callback_arg) -> torch.Tensor:
+    device, lock = common["device"], common["lock"]
+    chunk = tensor_chunk(mix)
+    batch, channels, length = chunk.shape
+    seg, segment_length, stride, offsets = _segment_plan(model, length, common["overlap"], common["segment"])
+    # the leaf pads to int(segment * sr) when a segment override is given, else to the training length
+    valid_length = int(common["segment"] * model.samplerate) if common["segment"] is not None else model.valid_length(segment_length)
+    if valid_length > model.segment_length:
+        raise ValueError(f"Given length {valid_length} is longer than training length {model.segment_length}")
+    weight = _transition_weight(segment_length, common["transition_power"], device).to(torch.float32).contiguous()
+    S = len(model.sources)
+    out = torch.empty(batch, S, channels, length, device=mix.device, dtype=torch.float32)
+    iterator = offsets
+    bar = None
+    if common["progress"]:
+        import tqdm
+        scale = float(format(stride / model.samplerate, ".2f"))
+        bar = tqdm.tqdm(total=len(offsets) * batch, unit_scale=scale, ncols=120, unit="seconds")
+
+    def events(offset):
+        if callback is not None:
+            arg = _with(callback_arg, segment_offset=offset)
+            with lock:
+                callback(_with(arg, state="start"))
+            with lock:
+                callback(_with(arg, state="end"))
+        if bar is not None:
+            bar.update(1)
+
+    for b in range(batch):
+        base = chunk.tensor[b].to(device=device, dtype=torch.float32).contiguous()       # whole track resident in HBM
+        acc = torch.zeros(S * channels, length, device=device, dtype=torch.float32)
+        device_split_accumulate(model, base, chunk.offset, length, iterator, segment_length, valid_length, weight, acc, 0, events)
+        device_split_finish(acc, 0, length, offsets, segment_length, weight)
+        out[b] = acc.view(S, channels, length).to(mix.device)
+    if bar is not None:
+        bar.close()
+    return out
