@@ -24,6 +24,11 @@ class MiConfig(C.Structure):
                 ("reserved", C.c_int32)]
 
 
+class MiProfileRow(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("launches", C.c_int64), ("ms", C.c_double), ("flops", C.c_double),
+                ("bytes", C.c_double)]
+
+
 class MiConvDesc(C.Structure):
     """mi_conv_desc of demucs_amd/csrc/gemm_conv.h (field order must match)."""
     _fields_ = [
@@ -48,6 +53,8 @@ SIGNATURES = {
     "mi_model_destroy": (None, [C.c_void_p]),
     "mi_model_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "mi_model_tap": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.c_void_p]),
+    "mi_profile_begin": (C.c_int, [C.c_void_p]),
+    "mi_profile_end": (C.c_int, [C.c_void_p, C.POINTER(MiProfileRow), C.c_int32, C.POINTER(C.c_int32), C.c_void_p]),
     "mi_model_device_bytes": (C.c_int64, [C.c_void_p]),
     "mi_segments_gather": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
                                      C.c_void_p]),

@@ -105,6 +105,28 @@ int mi_model_tap(void *handle, const char *name, float *dst_dev, int32_t B, int6
     return MI_OK;
 }
 
+int mi_profile_begin(void *handle) {
+    if (!handle) return set_error(MI_EINVAL, "mi_profile_begin: null handle");
+    ((Model *)handle)->prof.begin();
+    return MI_OK;
+}
+
+int mi_profile_end(void *handle, mi_profile_row *rows, int32_t max_rows, int32_t *n_rows, void *stream) {
+    if (!handle || !rows || !n_rows) return set_error(MI_EINVAL, "mi_profile_end: null argument");
+    Model *m = (Model *)handle;
+    MI_TRY(m->prof.end((hipStream_t)stream));
+    int n = 0;
+    for (const ProfRow &r : m->prof.rows) {
+        if (!r.launches || n >= max_rows) continue;
+        mi_profile_row &o = rows[n++];
+        memset(&o, 0, sizeof(o));
+        strncpy(o.name, r.name, sizeof(o.name) - 1);
+        o.launches = r.launches; o.ms = r.ms; o.flops = r.flops; o.bytes = r.bytes;
+    }
+    *n_rows = n;
+    return MI_OK;
+}
+
 int64_t mi_model_device_bytes(void *handle) { return handle ? ((Model *)handle)->device_bytes : 0; }
 
 int mi_segments_gather(const float *track_dev, int64_t track_len, int32_t channels, const int64_t *starts_dev, int32_t B,

@@ -41,8 +41,31 @@ struct TrLayerW {
     float *gamma1 = nullptr, *gamma2 = nullptr;
 };
 
+// Per-kernel-class device timing with HIP events on the launch stream (bench.py's roofline leg).
+struct ProfRow {
+    int cls = 0;
+    char name[48] = "";
+    long long launches = 0;
+    double ms = 0.0, flops = 0.0, bytes = 0.0;
+};
+struct Profiler {
+    bool on = false;
+    struct Pending { int cls; hipEvent_t a, b; double flops, bytes; };
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> pool;
+    ProfRow rows[128];
+    hipEvent_t get();
+    void begin();
+    int end(hipStream_t st);
+    ~Profiler();
+};
+
 struct Model {
     mi_config cfg{};
+    Profiler prof;
+    int conv(const mi_conv_desc &d, hipStream_t st);
+    int attn(const float *q, const float *k, const float *v, float *o, int B, int Tq, int Tk, int64_t q_bs, int64_t kv_bs,
+             int64_t o_bs, hipStream_t st);
     int S = 0, SL = 0, T = 0, Lt[5] = {};
     int64_t device_bytes = 0;
     std::vector<void *> allocs;

@@ -44,6 +44,85 @@ Model::~Model() {
 }
 
 // ------------------------------------------------------------------------------------------------
+// profiler: one HIP event pair per launch of the instrumented kernel classes, on the launch stream
+// ------------------------------------------------------------------------------------------------
+hipEvent_t Profiler::get() {
+    if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+void Profiler::begin() {
+    for (auto &r : rows) r = ProfRow();
+    on = true;
+}
+int Profiler::end(hipStream_t st) {
+    on = false;
+    MI_HIP(hipStreamSynchronize(st));
+    for (auto &p : pending) {
+        float ms = 0.f;
+        MI_HIP(hipEventElapsedTime(&ms, p.a, p.b));
+        ProfRow &r = rows[p.cls];
+        r.cls = p.cls; r.launches++; r.ms += ms; r.flops += p.flops; r.bytes += p.bytes;
+        pool.push_back(p.a); pool.push_back(p.b);
+    }
+    pending.clear();
+    return MI_OK;
+}
+Profiler::~Profiler() {
+    for (auto &p : pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    for (auto e : pool) (void)hipEventDestroy(e);
+}
+
+static const char *kEpiNames[6] = {"linear", "glu", "bias_stats", "stats_only", "gn_glu", "convtr"};
+
+// class id of a conv launch: epilogue x tile x prologue
+static int conv_class(const mi_conv_desc &d, int tile) {
+    const int ti = tile == 32 ? 0 : tile == 64 ? 1 : tile == 96 ? 2 : 3;
+    return d.epi * 8 + ti * 2 + (d.pro ? 1 : 0);
+}
+
+int Model::conv(const mi_conv_desc &d, hipStream_t st) {
+    if (!prof.on) return launch_conv(d, st);
+    const int tile = d.tile_m ? d.tile_m : conv_pick_tile(d.M);
+    const int cls = conv_class(d, tile);
+    const double N = (double)d.B * d.O1 * d.O2;
+    // algorithmic work: 2*M*K flops per output column; bytes = input tensor + output tensor + weights, once each
+    const double cin = (double)d.K / std::max(1, d.K / std::max(1, (int)(d.x_bstride / ((int64_t)d.D1 * d.D2))));
+    const double in_bytes = 4.0 * (double)d.B * (double)d.x_bstride;
+    double out_rows = d.M;
+    if (d.epi == MI_EPI_GLU || d.epi == MI_EPI_GN_GLU) out_rows = d.M / 2;
+    if (d.epi == MI_EPI_CONVTR) out_rows = d.M;                     // 4 phases x Cout rows, each column scattered once
+    if (d.epi == MI_EPI_STATS_ONLY) out_rows = 0;
+    double bytes = in_bytes + 4.0 * out_rows * N + 4.0 * (double)d.M * d.K;
+    if (d.flags & MI_FLAG_RES || d.epi == MI_EPI_GN_GLU) bytes += 4.0 * out_rows * N;
+    (void)cin;
+    Profiler::Pending p{cls, prof.get(), prof.get(), 2.0 * d.M * (double)d.K * N, bytes};
+    MI_HIP(hipEventRecord(p.a, st));
+    const int r = launch_conv(d, st);
+    MI_HIP(hipEventRecord(p.b, st));
+    prof.pending.push_back(p);
+    ProfRow &row = prof.rows[cls];
+    if (!row.name[0]) snprintf(row.name, sizeof(row.name), "conv_gemm<%s,tile%d%s>", kEpiNames[d.epi], tile, d.pro ? ",gn_gelu" : "");
+    return r;
+}
+
+int Model::attn(const float *q, const float *k, const float *v, float *o, int B, int Tq, int Tk, int64_t q_bs, int64_t kv_bs,
+                int64_t o_bs, hipStream_t st) {
+    if (!prof.on) return launch_attention(q, k, v, o, B, 8, Tq, Tk, q_bs, kv_bs, o_bs, st);
+    const int cls = 100;
+    // QK^T and PV: 2 * 2 * Tq * Tk * 64 flops per head; bytes = q, k, v read once + o written
+    Profiler::Pending p{cls, prof.get(), prof.get(), 4.0 * B * 8 * (double)Tq * Tk * 64.0,
+                        4.0 * B * 512.0 * (2.0 * Tq + 2.0 * Tk)};
+    MI_HIP(hipEventRecord(p.a, st));
+    const int r = launch_attention(q, k, v, o, B, 8, Tq, Tk, q_bs, kv_bs, o_bs, st);
+    MI_HIP(hipEventRecord(p.b, st));
+    prof.pending.push_back(p);
+    snprintf(prof.rows[cls].name, sizeof(prof.rows[cls].name), "attention_kernel");
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------------
 // weight lookup and packing
 // ------------------------------------------------------------------------------------------------
 struct WeightTable {
@@ -435,17 +514,17 @@ int Model::run_dconv(const DConvW &w, int C, const Geo &g, float *x, float *tmp,
         MI_HIP(hipMemsetAsync(stats, 0, sizeof(double) * 2 * kStatSlots * rows, st));
         mi_conv_desc d = base_desc(l.conv3, l.ktab3, src, (int64_t)C * P, g);
         d.epi = MI_EPI_BIAS_STATS; d.y = hidden; d.y_bstride = (int64_t)h * P; d.y_cstride = P; d.stats = stats;
-        MI_TRY(launch_conv(d, st));
+        MI_TRY(conv(d, st));
         MI_TRY(launch_finalize_stats(stats, rows, cnt_row * h, 1e-5f, 0, st1, nullptr, st));
         MI_HIP(hipMemsetAsync(stats, 0, sizeof(double) * 2 * kStatSlots * rows, st));
         mi_conv_desc e = base_desc(l.conv1, l.ktab1, hidden, (int64_t)h * P, g);
         e.pro = 1; e.pro_stats = (const float *)st1; e.pro_w = l.gn1_w; e.pro_b = l.gn1_b;
         e.epi = MI_EPI_STATS_ONLY; e.stats = stats;
-        MI_TRY(launch_conv(e, st));
+        MI_TRY(conv(e, st));
         MI_TRY(launch_finalize_stats(stats, rows, cnt_row * 2 * C, 1e-5f, 0, st2, nullptr, st));
         e.epi = MI_EPI_GN_GLU; e.stats = nullptr; e.gn_stats = (const float *)st2; e.gn_w = l.gn2_w; e.gn_b = l.gn2_b;
         e.scale = l.ls; e.res = src; e.y = dst; e.y_bstride = (int64_t)C * P; e.y_cstride = P;
-        MI_TRY(launch_conv(e, st));
+        MI_TRY(conv(e, st));
         std::swap(src, dst);
     }
     return MI_OK;   // two layers: result is back in x
@@ -467,9 +546,9 @@ int Model::run_tr_layer(int br, int k, int B, const float *x, const float *other
     if (!cross) {
         mi_conv_desc d = base_desc(l.qkv_proj, tr_ktab512[br], ln, (int64_t)512 * Tq, gq);
         d.epi = MI_EPI_LINEAR; d.y = qkv; d.y_bstride = (int64_t)1536 * Tq; d.y_cstride = Tq;
-        MI_TRY(launch_conv(d, st));
+        MI_TRY(conv(d, st));
     MI_STAGE("tr step 2");
-        MI_TRY(launch_attention(qkv, qkv + (size_t)512 * Tq, qkv + (size_t)1024 * Tq, att, B, 8, Tq, Tq, (int64_t)1536 * Tq,
+        MI_TRY(attn(qkv, qkv + (size_t)512 * Tq, qkv + (size_t)1024 * Tq, att, B, Tq, Tq, (int64_t)1536 * Tq,
                                 (int64_t)1536 * Tq, (int64_t)512 * Tq, st));
     MI_STAGE("tr step 3");
     } else {
@@ -477,14 +556,14 @@ int Model::run_tr_layer(int br, int k, int B, const float *x, const float *other
     MI_STAGE("tr step 4");
         mi_conv_desc d = base_desc(l.q_proj, tr_ktab512[br], ln, (int64_t)512 * Tq, gq);
         d.epi = MI_EPI_LINEAR; d.y = qkv; d.y_bstride = (int64_t)512 * Tq; d.y_cstride = Tq;
-        MI_TRY(launch_conv(d, st));
+        MI_TRY(conv(d, st));
     MI_STAGE("tr step 5");
         float *kv = qkv + (size_t)B * 512 * Tq;
         mi_conv_desc e = base_desc(l.kv_proj, tr_ktab512[1 - br], ln2, (int64_t)512 * Tk, gk);
         e.epi = MI_EPI_LINEAR; e.y = kv; e.y_bstride = (int64_t)1024 * Tk; e.y_cstride = Tk;
-        MI_TRY(launch_conv(e, st));
+        MI_TRY(conv(e, st));
     MI_STAGE("tr step 6");
-        MI_TRY(launch_attention(qkv, kv, kv + (size_t)512 * Tk, att, B, 8, Tq, Tk, (int64_t)512 * Tq, (int64_t)1024 * Tk,
+        MI_TRY(attn(qkv, kv, kv + (size_t)512 * Tk, att, B, Tq, Tk, (int64_t)512 * Tq, (int64_t)1024 * Tk,
                                 (int64_t)512 * Tq, st));
     MI_STAGE("tr step 7");
     }
@@ -492,7 +571,7 @@ int Model::run_tr_layer(int br, int k, int B, const float *x, const float *other
         mi_conv_desc d = base_desc(l.out_proj, tr_ktab512[br], att, (int64_t)512 * Tq, gq);
         d.epi = MI_EPI_LINEAR; d.flags = MI_FLAG_SCALE | MI_FLAG_RES; d.scale = l.gamma1; d.res = x;
         d.y = x1; d.y_bstride = (int64_t)512 * Tq; d.y_cstride = Tq;
-        MI_TRY(launch_conv(d, st));
+        MI_TRY(conv(d, st));
     MI_STAGE("tr step 8");
     }
     MI_TRY(launch_layernorm_cf(x1, B, 512, Tq, l.norm_w[cross ? 2 : 1], l.norm_b[cross ? 2 : 1], nullptr, ln, st));
@@ -500,12 +579,12 @@ int Model::run_tr_layer(int br, int k, int B, const float *x, const float *other
     {
         mi_conv_desc d = base_desc(l.lin1, tr_ktab512[br], ln, (int64_t)512 * Tq, gq);
         d.epi = MI_EPI_LINEAR; d.flags = MI_FLAG_GELU; d.y = ffh; d.y_bstride = (int64_t)2048 * Tq; d.y_cstride = Tq;
-        MI_TRY(launch_conv(d, st));
+        MI_TRY(conv(d, st));
     MI_STAGE("tr step 10");
         mi_conv_desc e = base_desc(l.lin2, tr_ktab2048[br], ffh, (int64_t)2048 * Tq, gq);
         e.epi = MI_EPI_LINEAR; e.flags = MI_FLAG_SCALE | MI_FLAG_RES; e.scale = l.gamma2; e.res = x1;
         e.y = x2; e.y_bstride = (int64_t)512 * Tq; e.y_cstride = Tq;
-        MI_TRY(launch_conv(e, st));
+        MI_TRY(conv(e, st));
     MI_STAGE("tr step 11");
     }
     // norm_out: GroupNorm(1, 512) over (tokens, channels) per item (transformer.py:258-268)
@@ -546,14 +625,14 @@ int Model::forward(const float *mix, float *out, int B, hipStream_t st) {
             mi_conv_desc d = base_desc(enc[i].conv, enc[i].ktab_conv, xf, Cin * Pin, gin);
             d.O1 = kFr[i + 1]; d.S1 = 4; d.epi = MI_EPI_LINEAR; d.flags = MI_FLAG_GELU;
             d.y = w_a; d.y_bstride = C * P; d.y_cstride = P;
-            MI_TRY(launch_conv(d, st));
+            MI_TRY(conv(d, st));
             MI_STAGE("enc conv done");
             MI_TRY(run_dconv(enc[i].dconv, C, go, w_a, w_b, w_h, w_stats, w_st1, w_st2, st));
             MI_STAGE("enc dconv done");
             mi_conv_desc r = base_desc(enc[i].rewrite, enc[i].ktab_rw, w_a, C * P, go);
             r.epi = MI_EPI_GLU; r.y = w_skip[i]; r.y_bstride = C * P; r.y_cstride = P;
             if (i == 0) { r.flags = MI_FLAG_EMB; r.emb = freq_emb; }
-            MI_TRY(launch_conv(r, st));
+            MI_TRY(conv(r, st));
             xf = w_skip[i];
             MI_STAGE("enc rewrite done");
         }
@@ -563,11 +642,11 @@ int Model::forward(const float *mix, float *out, int B, hipStream_t st) {
             mi_conv_desc d = base_desc(tenc[i].conv, tenc[i].ktab_conv, xt, (int64_t)Cint * Lt[i], gin);
             d.O2 = Lt[i + 1]; d.S2 = 4; d.epi = MI_EPI_LINEAR; d.flags = MI_FLAG_GELU;
             d.y = w_ta; d.y_bstride = C * P; d.y_cstride = P;
-            MI_TRY(launch_conv(d, st));
+            MI_TRY(conv(d, st));
             MI_TRY(run_dconv(tenc[i].dconv, C, go, w_ta, w_tb, w_th, w_stats_t, w_st1_t, w_st2_t, st));
             mi_conv_desc r = base_desc(tenc[i].rewrite, tenc[i].ktab_rw, w_ta, C * P, go);
             r.epi = MI_EPI_GLU; r.y = w_skip_t[i]; r.y_bstride = C * P; r.y_cstride = P;
-            MI_TRY(launch_conv(r, st));
+            MI_TRY(conv(r, st));
             xt = w_skip_t[i];
             MI_STAGE("tenc layer done");
         }
@@ -579,7 +658,7 @@ int Model::forward(const float *mix, float *out, int B, hipStream_t st) {
         const Geo g{B, 1, P, 0};
         mi_conv_desc d = base_desc(chan[br], chan_ktab[br], br ? xt : xf, (int64_t)384 * P, g);
         d.epi = MI_EPI_LINEAR; d.y = w_tr_x1[br]; d.y_bstride = (int64_t)512 * P; d.y_cstride = P;
-        MI_TRY(launch_conv(d, st));
+        MI_TRY(conv(d, st));
         MI_TRY(launch_layernorm_cf(w_tr_x1[br], B, 512, P, norm_in_w[br], norm_in_b[br], pos_emb[br], w_tr_x[br][0], st));
     }
     MI_STAGE("upsample + norm_in done");
@@ -597,7 +676,7 @@ int Model::forward(const float *mix, float *out, int B, hipStream_t st) {
         mi_conv_desc d = base_desc(chan[2 + br], chan_ktab[2 + br], w_tr_x[br][cur[br]], (int64_t)512 * P, g);
         d.epi = MI_EPI_LINEAR; d.flags = MI_FLAG_RES; d.res = br ? w_skip_t[3] : w_skip[3];
         d.y = br ? dtin : din; d.y_bstride = (int64_t)384 * P; d.y_cstride = P;
-        MI_TRY(launch_conv(d, st));
+        MI_TRY(conv(d, st));
     }
     // ---- decoders ----------------------------------------------------------------------------------
     for (int j = 0; j < 4; ++j) {
@@ -608,7 +687,7 @@ int Model::forward(const float *mix, float *out, int B, hipStream_t st) {
             const int64_t P = (int64_t)Fr * T;
             mi_conv_desc r = base_desc(dec[j].rewrite, dec[j].ktab_rw, din, C * P, g);
             r.epi = MI_EPI_GLU; r.y = w_a; r.y_bstride = C * P; r.y_cstride = P;
-            MI_TRY(launch_conv(r, st));
+            MI_TRY(conv(r, st));
             MI_TRY(run_dconv(dec[j].dconv, C, g, w_a, w_b, w_h, w_stats, w_st1, w_st2, st));
             const int Cout = last ? 4 * S : kCh[2 - j];
             mi_conv_desc t = base_desc(dec[j].convtr, dec[j].ktab_tr, w_a, C * P, g);
@@ -617,7 +696,7 @@ int Model::forward(const float *mix, float *out, int B, hipStream_t st) {
             if (last) t.y = w_yspec;
             else { t.flags |= MI_FLAG_GELU | MI_FLAG_RES; t.res = w_skip[2 - j]; t.y = din; }
             // din is free to overwrite: the rewrite conv that read it has completed (same stream)
-            MI_TRY(launch_conv(t, st));
+            MI_TRY(conv(t, st));
             MI_STAGE("dec freq layer done");
         }
         {   // time branch
@@ -625,7 +704,7 @@ int Model::forward(const float *mix, float *out, int B, hipStream_t st) {
             const Geo g{B, 1, L, 0};
             mi_conv_desc r = base_desc(tdec[j].rewrite, tdec[j].ktab_rw, dtin, (int64_t)C * L, g);
             r.epi = MI_EPI_GLU; r.y = w_ta; r.y_bstride = (int64_t)C * L; r.y_cstride = L;
-            MI_TRY(launch_conv(r, st));
+            MI_TRY(conv(r, st));
             MI_TRY(run_dconv(tdec[j].dconv, C, g, w_ta, w_tb, w_th, w_stats_t, w_st1_t, w_st2_t, st));
             const int Cout = last ? 2 * S : kCh[2 - j];
             mi_conv_desc t = base_desc(tdec[j].convtr, tdec[j].ktab_tr, w_ta, (int64_t)C * L, g);
@@ -633,7 +712,7 @@ int Model::forward(const float *mix, float *out, int B, hipStream_t st) {
             t.y_cstride = Lout; t.y_bstride = (int64_t)Cout * Lout;
             if (last) t.y = w_ytime;
             else { t.flags |= MI_FLAG_GELU | MI_FLAG_RES; t.res = w_skip_t[2 - j]; t.y = dtin; }
-            MI_TRY(launch_conv(t, st));
+            MI_TRY(conv(t, st));
         }
     }
     MI_STAGE("decoders done");

@@ -153,6 +153,19 @@ class HTDemucs:
     def device_bytes(self) -> int:
         return int(_lib.load().mi_model_device_bytes(C.c_void_p(self._ensure_handle())))
 
+    def profile_begin(self) -> None:
+        _lib.check(_lib.load().mi_profile_begin(C.c_void_p(self._ensure_handle())), "mi_profile_begin")
+
+    def profile_end(self):
+        """[{name, launches, ms, flops, bytes}] per kernel class since profile_begin (synchronises)."""
+        rows = (_lib.MiProfileRow * 128)()
+        n = C.c_int32()
+        with torch.cuda.device(self._device):
+            _lib.check(_lib.load().mi_profile_end(C.c_void_p(self._ensure_handle()), rows, 128, C.byref(n),
+                                                  C.c_void_p(_lib.current_stream_ptr())), "mi_profile_end")
+        return [dict(name=rows[i].name.decode(), launches=rows[i].launches, ms=rows[i].ms, flops=rows[i].flops,
+                     bytes=rows[i].bytes) for i in range(n.value)]
+
     def tap(self, name: str, batch: int) -> torch.Tensor:
         """Copy of an internal activation of the last forward (parity tests), shape (batch, numel)."""
         lib, h, n = _lib.load(), C.c_void_p(self._ensure_handle()), C.c_int64()

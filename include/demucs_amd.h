@@ -66,6 +66,18 @@ int mi_model_forward(void *handle, const float *mix_dev, float *out_dev, int32_t
  * (transformer outputs, channel-first), "yspec", "ytime" (decoder outputs before iSTFT). */
 int mi_model_tap(void *handle, const char *name, float *dst_dev, int32_t B, int64_t *numel_per_item, void *stream);
 
+/* Per-kernel-class device timing for the roofline report: between begin and end every launch of
+ * the conv-GEMM and attention kernels made by mi_model_forward is bracketed by a HIP event pair
+ * on the launch stream; end synchronises the stream and returns one row per kernel class with
+ * the summed duration and the ALGORITHMIC flops / bytes of those launches. */
+typedef struct mi_profile_row {
+    char name[48];
+    int64_t launches;
+    double ms, flops, bytes;
+} mi_profile_row;
+int mi_profile_begin(void *handle);
+int mi_profile_end(void *handle, mi_profile_row *rows, int32_t max_rows, int32_t *n_rows, void *stream);
+
 /* Device bytes held by the handle (weights + workspace). */
 int64_t mi_model_device_bytes(void *handle);
 
