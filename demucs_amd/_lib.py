@@ -43,7 +43,7 @@ class MiConvDesc(C.Structure):
         ("bias", C.c_void_p), ("scale", C.c_void_p), ("res", C.c_void_p), ("emb", C.c_void_p),
         ("y", C.c_void_p), ("y_bstride", C.c_int64), ("y_cstride", C.c_int64),
         ("stats", C.c_void_p), ("gn_stats", C.c_void_p), ("gn_w", C.c_void_p), ("gn_b", C.c_void_p),
-        ("out_len", C.c_int32), ("tile_m", C.c_int32),
+        ("out_len", C.c_int32), ("tile_m", C.c_int32), ("plain", C.c_int32), ("reserved", C.c_int32),
     ]
 
 
@@ -67,6 +67,8 @@ SIGNATURES = {
     "mi_conv_forward": (C.c_int, [C.POINTER(MiConvDesc), C.c_void_p]),
     "mi_attention": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_void_p]),
+    "mi_gn_gelu": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                             C.c_void_p, C.c_void_p]),
     "mi_layernorm_cf": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p]),
     "mi_last_error": (C.c_char_p, []),

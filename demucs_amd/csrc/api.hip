@@ -197,6 +197,13 @@ int mi_attention(const float *q_dev, const float *k_dev, const float *v_dev, flo
                             (hipStream_t)stream);
 }
 
+int mi_gn_gelu(float *x_dev, int32_t B, int32_t C, int32_t C_alloc, int32_t D1, int32_t D2, int32_t row_mode, const float *stats_dev,
+               const float *w_dev, const float *b_dev, void *stream) {
+    MI_REQUIRE(x_dev && stats_dev && w_dev && b_dev && B > 0 && C > 0 && D1 > 0 && D2 > 0, "mi_gn_gelu: bad argument");
+    MI_REQUIRE(C_alloc >= C, "mi_gn_gelu: C_alloc < C");
+    return launch_gn_gelu(x_dev, B, C, C_alloc, D1, D2, row_mode, (const float2 *)stats_dev, w_dev, b_dev, (hipStream_t)stream);
+}
+
 int mi_layernorm_cf(const float *x_dev, int32_t B, int32_t C, int32_t T, const float *w_dev, const float *b_dev,
                     const float *add_dev, float *y_dev, void *stream) {
     MI_REQUIRE(x_dev && w_dev && b_dev && y_dev, "mi_layernorm_cf: null argument");

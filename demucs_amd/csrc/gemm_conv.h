@@ -44,7 +44,7 @@ typedef struct mi_conv_desc {
     const float *x;
     int64_t x_bstride;
     int32_t B, D1, D2, O1, O2, S1, S2;
-    /* prologue: 0 none; 1: gelu((x - mean[row]) * rstd[row] * pro_w[ci] + pro_b[ci]) */
+    /* prologue: must be 0 (the GroupNorm+GELU of the DConv hidden tensor runs as its own pass) */
     int32_t pro;
     const float *pro_stats; /* float2 [rows] (mean, rstd) */
     const float *pro_w, *pro_b;
@@ -62,6 +62,9 @@ typedef struct mi_conv_desc {
     const float *gn_w, *gn_b; /* [Mpad] packed row order                                 */
     int32_t out_len;        /* CONVTR: valid output length along the scattered axis      */
     int32_t tile_m;         /* 0 = choose automatically; else 32 / 64 / 96 / 128         */
+    int32_t plain;          /* 1: the gather is the identity over input channels (1x1 conv / linear with channel
+                               stride O1*O2): enables the table-free float4 loader when shapes allow             */
+    int32_t reserved;
 } mi_conv_desc;
 
 #ifdef __cplusplus

@@ -33,7 +33,17 @@ __device__ __forceinline__ ColInfo decompose(int n, int N, int P, int O2) {
     return c;
 }
 
-template <int WM, int WN, int TM, int TN, int PRO, int EPI>
+// B-operand gather for one element: branch-free (invalid taps read x[0] and are zeroed by a select)
+__device__ __forceinline__ float gather_b(const mi_conv_desc &d, const mi_ktab_entry e, const float *xcol, int i1b, int i2b,
+                                          bool colvalid, bool &ok) {
+    const int i1 = i1b + e.d1, i2 = i2b + e.d2;
+    ok = colvalid && (unsigned)i1 < (unsigned)d.D1 && (unsigned)i2 < (unsigned)d.D2;
+    const float *p = ok ? xcol + e.off : d.x;
+    return *p;
+}
+
+// PLAIN = 1x1 / linear layer with K % 16 == 0 and (O1*O2) % 4 == 0: no gather table, float4 activation loads.
+template <int WM, int WN, int TM, int TN, int EPI, bool PLAIN>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const mi_conv_desc d, const int N, const int MT) {
     constexpr int BM = WM * TM * 32;
     static_assert(WN * TN * 32 == BN, "block N tile is 128");
@@ -50,58 +60,61 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const mi_conv_desc d, co
     const int m0 = mt * BM, n0 = nt * BN;
     const int P = d.O1 * d.O2;
 
-    // ---- B loader: this thread owns column (tid & 127), rows khalf + 2*j ------------------------
+    // ---- A loader: BK x BM floats as float4, thread-linear ---------------------------------------
+    constexpr int A_F4 = BK * BM / 4, A_FULL = A_F4 / 256, A_REM = A_F4 % 256;
+    constexpr int A_SLOTS = A_FULL + (A_REM ? 1 : 0);
+    static_assert(A_SLOTS <= 2, "A tile fits two float4 per thread");
+    const int aidx0 = tid < A_F4 ? tid : 0, aidx1 = (tid + 256 < A_F4) ? tid + 256 : 0;
+    const int ar0 = aidx0 / (BM / 4), ac0 = (aidx0 % (BM / 4)) * 4;
+    const int ar1 = aidx1 / (BM / 4), ac1 = (aidx1 % (BM / 4)) * 4;
+    const bool a_on0 = tid < A_F4, a_on1 = tid + 256 < A_F4;
+    const float *ap0 = d.wt + (size_t)ar0 * d.Mpad + m0 + ac0;
+    const float *ap1 = d.wt + (size_t)ar1 * d.Mpad + m0 + ac1;
+    const size_t a_step = (size_t)BK * d.Mpad;
+
+    // ---- B loader ----------------------------------------------------------------------------------
+    // generic: this thread owns column (tid & 127), rows khalf + 2*j;  plain: 4 columns x rows r, r + 8
     const int khalf = wave >> 1;
-    const ColInfo lc = decompose(n0 + (tid & 127), N, P, d.O2);
+    const ColInfo lc = decompose(n0 + (PLAIN ? (tid & 31) * 4 : (tid & 127)), N, P, d.O2);
     const int i1b = lc.o1 * d.S1, i2b = lc.o2 * d.S2;
-    const float *xcol = d.x + (size_t)lc.b * d.x_bstride + (size_t)i1b * d.D2 + i2b;
-    float pmean = 0.f, prstd = 0.f;
-    if (PRO == 1) {
-        const int row = d.row_mode ? lc.b * d.O1 + lc.o1 : lc.b;
-        const float2 st = reinterpret_cast<const float2 *>(d.pro_stats)[row];
-        pmean = st.x; prstd = st.y;
-    }
+    const float *xcol = d.x + (size_t)lc.b * d.x_bstride + (PLAIN ? (size_t)lc.p : (size_t)i1b * d.D2 + i2b);
+    const int prow = tid >> 5;                                   // plain: first row of this thread
+    const float *bp0 = lc.valid ? xcol + (size_t)prow * P : d.x; // plain row pointers (channel stride = P)
+    const float *bp1 = lc.valid ? xcol + (size_t)(prow + 8) * P : d.x;
+    const size_t b_step = lc.valid ? (size_t)BK * P : 0;
 
+    float4 areg0 = make_float4(0.f, 0.f, 0.f, 0.f), areg1 = areg0, bq0 = areg0, bq1 = areg0;
     float breg[8];
-    float4 areg[(BK * BM / 4 + 255) / 256];
-    constexpr int A_ITERS = (BK * BM / 4 + 255) / 256;
+    bool bok[8];
 
-    auto load_tile = [&](int kt) {
-        const int k0 = kt * BK;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int k = k0 + khalf + 2 * j;                    // wave-uniform -> scalar table load
-            const mi_ktab_entry e = d.ktab[k];
-            const int i1 = i1b + e.d1, i2 = i2b + e.d2;
-            const bool ok = lc.valid && (unsigned)i1 < (unsigned)d.D1 && (unsigned)i2 < (unsigned)d.D2;
-            float v = ok ? xcol[e.off] : 0.f;
-            if (PRO == 1) {
-                const float w = d.pro_w[e.ci], bb = d.pro_b[e.ci];
-                v = ok ? gelu_exact((v - pmean) * prstd * w + bb) : 0.f;
-            }
-            breg[j] = v;
-        }
-#pragma unroll
-        for (int it = 0; it < A_ITERS; ++it) {
-            const int idx = tid + it * 256;
-            if (idx < BK * BM / 4) {
-                const int r = idx / (BM / 4), c4 = idx % (BM / 4);
-                areg[it] = *reinterpret_cast<const float4 *>(d.wt + (size_t)(k0 + r) * d.Mpad + m0 + c4 * 4);
-            }
-        }
-    };
-    auto store_tile = [&](int buf) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) Bs[buf][khalf + 2 * j][tid & 127] = breg[j];
-#pragma unroll
-        for (int it = 0; it < A_ITERS; ++it) {
-            const int idx = tid + it * 256;
-            if (idx < BK * BM / 4) {
-                const int r = idx / (BM / 4), c4 = idx % (BM / 4);
-                *reinterpret_cast<float4 *>(&As[buf][r][c4 * 4]) = areg[it];
-            }
-        }
-    };
+#define MI_LOAD_TILE(kt)                                                                              \
+    do {                                                                                              \
+        if (PLAIN) {                                                                                  \
+            bq0 = *reinterpret_cast<const float4 *>(bp0 + (size_t)(kt) * b_step);                     \
+            bq1 = *reinterpret_cast<const float4 *>(bp1 + (size_t)(kt) * b_step);                     \
+        } else {                                                                                      \
+            mi_ktab_entry ke[8];                                                                      \
+            _Pragma("unroll") for (int j = 0; j < 8; ++j) ke[j] = d.ktab[(kt) * BK + khalf + 2 * j];   \
+            _Pragma("unroll") for (int j = 0; j < 8; ++j)                                              \
+                breg[j] = gather_b(d, ke[j], xcol, i1b, i2b, lc.valid, bok[j]);                        \
+        }                                                                                             \
+        if (A_SLOTS >= 1) areg0 = *reinterpret_cast<const float4 *>(ap0 + (size_t)(kt) * a_step);     \
+        if (A_SLOTS >= 2) areg1 = *reinterpret_cast<const float4 *>(ap1 + (size_t)(kt) * a_step);     \
+    } while (0)
+
+#define MI_STORE_TILE(buf)                                                                            \
+    do {                                                                                              \
+        if (PLAIN) {                                                                                  \
+            if (!lc.valid) { bq0 = make_float4(0.f, 0.f, 0.f, 0.f); bq1 = bq0; }                      \
+            *reinterpret_cast<float4 *>(&Bs[buf][prow][(tid & 31) * 4]) = bq0;                        \
+            *reinterpret_cast<float4 *>(&Bs[buf][prow + 8][(tid & 31) * 4]) = bq1;                    \
+        } else {                                                                                      \
+            _Pragma("unroll") for (int j = 0; j < 8; ++j)                                              \
+                Bs[buf][khalf + 2 * j][tid & 127] = bok[j] ? breg[j] : 0.f;                            \
+        }                                                                                             \
+        if (A_SLOTS >= 1 && a_on0) *reinterpret_cast<float4 *>(&As[buf][ar0][ac0]) = areg0;           \
+        if (A_SLOTS >= 2 && a_on1) *reinterpret_cast<float4 *>(&As[buf][ar1][ac1]) = areg1;           \
+    } while (0)
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -113,29 +126,38 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const mi_conv_desc d, co
 
     const int nk = d.Kpad / BK;
     const int li = lane & 31, lh = lane >> 5;
-    load_tile(0);
-    store_tile(0);
+    MI_LOAD_TILE(0);
+    MI_STORE_TILE(0);
     __syncthreads();
     int cur = 0;
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) load_tile(kt + 1);
+        if (kt + 1 < nk) MI_LOAD_TILE(kt + 1);
+        // fragments double-buffered in registers: the reads of step s+1 are in flight under the MFMAs of step s
+        float af[2][TM], bf[2][TN];
+#pragma unroll
+        for (int a = 0; a < TM; ++a) af[0][a] = As[cur][lh][(wm * TM + a) * 32 + li];
+#pragma unroll
+        for (int b = 0; b < TN; ++b) bf[0][b] = Bs[cur][lh][(wn * TN + b) * 32 + li];
 #pragma unroll
         for (int s = 0; s < BK / 2; ++s) {
-            float af[TM], bf[TN];
+            if (s + 1 < BK / 2) {
 #pragma unroll
-            for (int a = 0; a < TM; ++a) af[a] = As[cur][2 * s + lh][(wm * TM + a) * 32 + li];
+                for (int a = 0; a < TM; ++a) af[(s + 1) & 1][a] = As[cur][2 * (s + 1) + lh][(wm * TM + a) * 32 + li];
 #pragma unroll
-            for (int b = 0; b < TN; ++b) bf[b] = Bs[cur][2 * s + lh][(wn * TN + b) * 32 + li];
+                for (int b = 0; b < TN; ++b) bf[(s + 1) & 1][b] = Bs[cur][2 * (s + 1) + lh][(wn * TN + b) * 32 + li];
+            }
 #pragma unroll
             for (int a = 0; a < TM; ++a)
 #pragma unroll
                 for (int b = 0; b < TN; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s & 1][a], bf[s & 1][b], acc[a][b], 0, 0, 0);
         }
-        if (kt + 1 < nk) store_tile(cur ^ 1);
+        if (kt + 1 < nk) MI_STORE_TILE(cur ^ 1);
         __syncthreads();
         cur ^= 1;
     }
+#undef MI_LOAD_TILE
+#undef MI_STORE_TILE
 
     // ---- epilogue ---------------------------------------------------------------------------------
     // acc[a][b][r] is C[m][n] with n = ncol(b) + li, m = mrow(a) + (r & 3) + 8 * (r >> 2) + 4 * lh
@@ -241,25 +263,25 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const mi_conv_desc d, co
 }
 
 // ---------------------------------------------------------------------------------------------
-template <int WM, int WN, int TM, int TN, int PRO, int EPI>
+template <int WM, int WN, int TM, int TN, int EPI, bool PLAIN>
 static int launch_cfg(const mi_conv_desc &d, hipStream_t st) {
     constexpr int BM = WM * TM * 32;
     const int64_t N64 = (int64_t)d.B * d.O1 * d.O2;
     MI_REQUIRE(N64 < (1ll << 31) - 256, "conv: too many output positions (%lld)", (long long)N64);
     MI_REQUIRE(d.Mpad % BM == 0, "conv: Mpad %d not a multiple of the %d-row tile", d.Mpad, BM);
     const int N = (int)N64, MT = d.Mpad / BM, NT = ceil_div(N, BN);
-    hipLaunchKernelGGL((conv_gemm_kernel<WM, WN, TM, TN, PRO, EPI>), dim3((unsigned)MT * NT), dim3(256), 0, st, d, N, MT);
+    hipLaunchKernelGGL((conv_gemm_kernel<WM, WN, TM, TN, EPI, PLAIN>), dim3((unsigned)MT * NT), dim3(256), 0, st, d, N, MT);
     MI_CHECK_LAUNCH();
     return MI_OK;
 }
 
-template <int PRO, int EPI>
+template <int EPI, bool PLAIN>
 static int launch_tile(const mi_conv_desc &d, int tile, hipStream_t st) {
     switch (tile) {
-        case 128: return launch_cfg<2, 2, 2, 2, PRO, EPI>(d, st);
-        case 96: return launch_cfg<1, 4, 3, 1, PRO, EPI>(d, st);
-        case 64: return launch_cfg<1, 4, 2, 1, PRO, EPI>(d, st);
-        case 32: return launch_cfg<1, 4, 1, 1, PRO, EPI>(d, st);
+        case 128: return launch_cfg<2, 2, 2, 2, EPI, PLAIN>(d, st);
+        case 96: return launch_cfg<1, 4, 3, 1, EPI, PLAIN>(d, st);
+        case 64: return launch_cfg<1, 4, 2, 1, EPI, PLAIN>(d, st);
+        case 32: return launch_cfg<1, 4, 1, 1, EPI, PLAIN>(d, st);
     }
     return set_error(MI_EINVAL, "conv: unsupported tile_m %d", tile);
 }
@@ -279,20 +301,23 @@ int launch_conv(const mi_conv_desc &d, hipStream_t st) {
     MI_REQUIRE(d.O2 >= 32 || d.row_mode == 0 || (d.epi != MI_EPI_BIAS_STATS && d.epi != MI_EPI_STATS_ONLY),
                "conv: statistics epilogue needs O2 >= 32");
     const int tile = d.tile_m ? d.tile_m : conv_pick_tile(d.M);
-    if (d.pro == 0) {
-        switch (d.epi) {
-            case MI_EPI_LINEAR: return launch_tile<0, MI_EPI_LINEAR>(d, tile, st);
-            case MI_EPI_GLU: return launch_tile<0, MI_EPI_GLU>(d, tile, st);
-            case MI_EPI_BIAS_STATS: return launch_tile<0, MI_EPI_BIAS_STATS>(d, tile, st);
-            case MI_EPI_CONVTR: return launch_tile<0, MI_EPI_CONVTR>(d, tile, st);
-        }
-    } else if (d.pro == 1) {
-        switch (d.epi) {
-            case MI_EPI_STATS_ONLY: return launch_tile<1, MI_EPI_STATS_ONLY>(d, tile, st);
-            case MI_EPI_GN_GLU: return launch_tile<1, MI_EPI_GN_GLU>(d, tile, st);
-        }
+    MI_REQUIRE(d.pro == 0, "conv: the fused GroupNorm+GELU prologue was replaced by launch_gn_gelu");
+    // plain fast path: a 1x1 / linear layer whose gather is the identity
+    const int64_t P = (int64_t)d.O1 * d.O2;
+    const bool plain = d.plain && d.K == d.Kpad && P % 4 == 0 && d.x_bstride % 4 == 0 && ((uintptr_t)d.x & 15) == 0 &&
+                       d.S1 == 1 && d.S2 == 1 && d.D1 == d.O1 && d.D2 == d.O2;
+#define MI_DISPATCH(E)                                              \
+    case E: return plain ? launch_tile<E, true>(d, tile, st) : launch_tile<E, false>(d, tile, st)
+    switch (d.epi) {
+        MI_DISPATCH(MI_EPI_LINEAR);
+        MI_DISPATCH(MI_EPI_GLU);
+        MI_DISPATCH(MI_EPI_BIAS_STATS);
+        MI_DISPATCH(MI_EPI_STATS_ONLY);
+        MI_DISPATCH(MI_EPI_GN_GLU);
+        MI_DISPATCH(MI_EPI_CONVTR);
     }
-    return set_error(MI_EINVAL, "conv: unsupported prologue/epilogue combination (%d, %d)", d.pro, d.epi);
+#undef MI_DISPATCH
+    return set_error(MI_EINVAL, "conv: unsupported epilogue %d", d.epi);
 }
 
 }  // namespace mi

@@ -29,6 +29,9 @@ int launch_layernorm_cf(const float *x, int B, int C, int T, const float *w, con
 int launch_gn_apply_cf(const float *x, int B, int C, int T, const float2 *stats, const float *w, const float *b, float *y,
                        hipStream_t st);
 
+int launch_gn_gelu(float *x, int B, int C, int Cs, int D1, int D2, int row_mode, const float2 *stats, const float *w, const float *b,
+                   hipStream_t st);
+
 // gemm_conv.hip
 int launch_conv(const mi_conv_desc &d, hipStream_t st);
 int conv_pick_tile(int M);

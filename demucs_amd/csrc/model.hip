@@ -79,7 +79,7 @@ static const char *kEpiNames[6] = {"linear", "glu", "bias_stats", "stats_only", 
 // class id of a conv launch: epilogue x tile x prologue
 static int conv_class(const mi_conv_desc &d, int tile) {
     const int ti = tile == 32 ? 0 : tile == 64 ? 1 : tile == 96 ? 2 : 3;
-    return d.epi * 8 + ti * 2 + (d.pro ? 1 : 0);
+    return d.epi * 8 + ti * 2 + (d.plain ? 1 : 0);
 }
 
 int Model::conv(const mi_conv_desc &d, hipStream_t st) {
@@ -88,7 +88,6 @@ int Model::conv(const mi_conv_desc &d, hipStream_t st) {
     const int cls = conv_class(d, tile);
     const double N = (double)d.B * d.O1 * d.O2;
     // algorithmic work: 2*M*K flops per output column; bytes = input tensor + output tensor + weights, once each
-    const double cin = (double)d.K / std::max(1, d.K / std::max(1, (int)(d.x_bstride / ((int64_t)d.D1 * d.D2))));
     const double in_bytes = 4.0 * (double)d.B * (double)d.x_bstride;
     double out_rows = d.M;
     if (d.epi == MI_EPI_GLU || d.epi == MI_EPI_GN_GLU) out_rows = d.M / 2;
@@ -96,14 +95,13 @@ int Model::conv(const mi_conv_desc &d, hipStream_t st) {
     if (d.epi == MI_EPI_STATS_ONLY) out_rows = 0;
     double bytes = in_bytes + 4.0 * out_rows * N + 4.0 * (double)d.M * d.K;
     if (d.flags & MI_FLAG_RES || d.epi == MI_EPI_GN_GLU) bytes += 4.0 * out_rows * N;
-    (void)cin;
     Profiler::Pending p{cls, prof.get(), prof.get(), 2.0 * d.M * (double)d.K * N, bytes};
     MI_HIP(hipEventRecord(p.a, st));
     const int r = launch_conv(d, st);
     MI_HIP(hipEventRecord(p.b, st));
     prof.pending.push_back(p);
     ProfRow &row = prof.rows[cls];
-    if (!row.name[0]) snprintf(row.name, sizeof(row.name), "conv_gemm<%s,tile%d%s>", kEpiNames[d.epi], tile, d.pro ? ",gn_gelu" : "");
+    if (!row.name[0]) snprintf(row.name, sizeof(row.name), "conv_gemm<%s,tile%d%s>", kEpiNames[d.epi], tile, d.plain ? ",1x1" : "");
     return r;
 }
 
@@ -229,8 +227,14 @@ int Model::load_dconv(const WeightTable &wt, const std::string &prefix, int C, i
         MI_TRY(pack_conv(w0, b0, h, 3 * C, false, &l.conv3));
         const int dil = 1 << d;
         MI_TRY(make_ktab(Gather{C, 1, 3, 1, dil, 0, dil, chan_stride, D2}, l.conv3.Kpad, &l.ktab3));
-        MI_TRY(pack_conv(w3, b3, 2 * C, h, true, &l.conv1));
-        MI_TRY(make_ktab(Gather{h, 1, 1, 1, 1, 0, 0, chan_stride, D2}, l.conv1.Kpad, &l.ktab1));
+        // the hidden tensor is stored with hp = round_up(h, 16) channels (extra channels stay zero), so the
+        // 1x1 conv sees K == Kpad and can take the table-free float4 loader
+        const int hp = round_up(h, 16);
+        std::vector<float> w3p((size_t)2 * C * hp, 0.f);
+        for (int m = 0; m < 2 * C; ++m)
+            for (int k = 0; k < h; ++k) w3p[(size_t)m * hp + k] = w3[(size_t)m * h + k];
+        MI_TRY(pack_conv(w3p.data(), b3, 2 * C, hp, true, &l.conv1));
+        MI_TRY(make_ktab(Gather{hp, 1, 1, 1, 1, 0, 0, chan_stride, D2}, l.conv1.Kpad, &l.ktab1));
         MI_TRY(pack_vec(g1w, h, h, false, &l.gn1_w));
         MI_TRY(pack_vec(g1b, h, h, false, &l.gn1_b));
         MI_TRY(pack_vec(g2w, 2 * C, l.conv1.Mpad, true, &l.gn2_w));
@@ -443,8 +447,11 @@ int Model::alloc_workspace() {
         big = std::max(big, std::max(nf, nt));
     }
     // scratch shared by all U-Net layers (largest layer: 48 x 512 x T)
-    MI_TRY(A(&w_a, big)); MI_TRY(A(&w_b, big)); MI_TRY(A(&w_c, big)); MI_TRY(A(&w_h, big / 8));
-    MI_TRY(A(&w_ta, big)); MI_TRY(A(&w_tb, big)); MI_TRY(A(&w_tc, big)); MI_TRY(A(&w_th, big / 8));
+    MI_TRY(A(&w_a, big)); MI_TRY(A(&w_b, big)); MI_TRY(A(&w_c, big)); MI_TRY(A(&w_h, big / 2));
+    MI_TRY(A(&w_ta, big)); MI_TRY(A(&w_tb, big)); MI_TRY(A(&w_tc, big)); MI_TRY(A(&w_th, big / 2));
+    // DConv hidden tensors carry round_up(C/8, 16) channels; the padding channels must read as zero
+    MI_HIP(hipMemset(w_h, 0, (big / 2) * B * sizeof(float)));
+    MI_HIP(hipMemset(w_th, 0, (big / 2) * B * sizeof(float)));
     const size_t Tf = 8 * (size_t)T, Tt = Lt[4];
     for (int br = 0; br < 2; ++br) {
         const size_t P = br ? Tt : Tf;
@@ -504,7 +511,7 @@ static mi_conv_desc base_desc(const PackedConv &pc, const mi_ktab_entry *ktab, c
 // DConv residual branch, in place on x[b][C][D1][D2] (uses tmp of the same size and hidden of size/8)
 int Model::run_dconv(const DConvW &w, int C, const Geo &g, float *x, float *tmp, float *hidden, double *stats, float2 *st1,
                      float2 *st2, hipStream_t st) {
-    const int h = C / 8;
+    const int h = C / 8, hp = round_up(h, 16);
     const int64_t P = (int64_t)g.D1 * g.D2;
     const int rows = g.row_mode ? g.B * g.D1 : g.B;
     const double cnt_row = g.row_mode ? (double)g.D2 : (double)P;
@@ -513,12 +520,13 @@ int Model::run_dconv(const DConvW &w, int C, const Geo &g, float *x, float *tmp,
         const DConvLayerW &l = w.l[dlayer];
         MI_HIP(hipMemsetAsync(stats, 0, sizeof(double) * 2 * kStatSlots * rows, st));
         mi_conv_desc d = base_desc(l.conv3, l.ktab3, src, (int64_t)C * P, g);
-        d.epi = MI_EPI_BIAS_STATS; d.y = hidden; d.y_bstride = (int64_t)h * P; d.y_cstride = P; d.stats = stats;
+        d.epi = MI_EPI_BIAS_STATS; d.y = hidden; d.y_bstride = (int64_t)hp * P; d.y_cstride = P; d.stats = stats;
         MI_TRY(conv(d, st));
         MI_TRY(launch_finalize_stats(stats, rows, cnt_row * h, 1e-5f, 0, st1, nullptr, st));
         MI_HIP(hipMemsetAsync(stats, 0, sizeof(double) * 2 * kStatSlots * rows, st));
-        mi_conv_desc e = base_desc(l.conv1, l.ktab1, hidden, (int64_t)h * P, g);
-        e.pro = 1; e.pro_stats = (const float *)st1; e.pro_w = l.gn1_w; e.pro_b = l.gn1_b;
+        MI_TRY(launch_gn_gelu(hidden, g.B, h, hp, g.D1, g.D2, g.row_mode, st1, l.gn1_w, l.gn1_b, st));
+        mi_conv_desc e = base_desc(l.conv1, l.ktab1, hidden, (int64_t)hp * P, g);
+        e.plain = 1;
         e.epi = MI_EPI_STATS_ONLY; e.stats = stats;
         MI_TRY(conv(e, st));
         MI_TRY(launch_finalize_stats(stats, rows, cnt_row * 2 * C, 1e-5f, 0, st2, nullptr, st));
@@ -545,6 +553,7 @@ int Model::run_tr_layer(int br, int k, int B, const float *x, const float *other
     MI_STAGE("tr step 1");
     if (!cross) {
         mi_conv_desc d = base_desc(l.qkv_proj, tr_ktab512[br], ln, (int64_t)512 * Tq, gq);
+        d.plain = 1;
         d.epi = MI_EPI_LINEAR; d.y = qkv; d.y_bstride = (int64_t)1536 * Tq; d.y_cstride = Tq;
         MI_TRY(conv(d, st));
     MI_STAGE("tr step 2");
@@ -555,11 +564,13 @@ int Model::run_tr_layer(int br, int k, int B, const float *x, const float *other
         MI_TRY(launch_layernorm_cf(other, B, 512, Tk, l.norm_w[1], l.norm_b[1], nullptr, ln2, st));
     MI_STAGE("tr step 4");
         mi_conv_desc d = base_desc(l.q_proj, tr_ktab512[br], ln, (int64_t)512 * Tq, gq);
+        d.plain = 1;
         d.epi = MI_EPI_LINEAR; d.y = qkv; d.y_bstride = (int64_t)512 * Tq; d.y_cstride = Tq;
         MI_TRY(conv(d, st));
     MI_STAGE("tr step 5");
         float *kv = qkv + (size_t)B * 512 * Tq;
         mi_conv_desc e = base_desc(l.kv_proj, tr_ktab512[1 - br], ln2, (int64_t)512 * Tk, gk);
+        e.plain = 1;
         e.epi = MI_EPI_LINEAR; e.y = kv; e.y_bstride = (int64_t)1024 * Tk; e.y_cstride = Tk;
         MI_TRY(conv(e, st));
     MI_STAGE("tr step 6");
@@ -569,6 +580,7 @@ int Model::run_tr_layer(int br, int k, int B, const float *x, const float *other
     }
     {   // x1 = x + gamma_1 * (out_proj(att) + b)
         mi_conv_desc d = base_desc(l.out_proj, tr_ktab512[br], att, (int64_t)512 * Tq, gq);
+        d.plain = 1;
         d.epi = MI_EPI_LINEAR; d.flags = MI_FLAG_SCALE | MI_FLAG_RES; d.scale = l.gamma1; d.res = x;
         d.y = x1; d.y_bstride = (int64_t)512 * Tq; d.y_cstride = Tq;
         MI_TRY(conv(d, st));
@@ -578,10 +590,12 @@ int Model::run_tr_layer(int br, int k, int B, const float *x, const float *other
     MI_STAGE("tr step 9");
     {
         mi_conv_desc d = base_desc(l.lin1, tr_ktab512[br], ln, (int64_t)512 * Tq, gq);
+        d.plain = 1;
         d.epi = MI_EPI_LINEAR; d.flags = MI_FLAG_GELU; d.y = ffh; d.y_bstride = (int64_t)2048 * Tq; d.y_cstride = Tq;
         MI_TRY(conv(d, st));
     MI_STAGE("tr step 10");
         mi_conv_desc e = base_desc(l.lin2, tr_ktab2048[br], ffh, (int64_t)2048 * Tq, gq);
+        e.plain = 1;
         e.epi = MI_EPI_LINEAR; e.flags = MI_FLAG_SCALE | MI_FLAG_RES; e.scale = l.gamma2; e.res = x1;
         e.y = x2; e.y_bstride = (int64_t)512 * Tq; e.y_cstride = Tq;
         MI_TRY(conv(e, st));
@@ -630,7 +644,7 @@ int Model::forward(const float *mix, float *out, int B, hipStream_t st) {
             MI_TRY(run_dconv(enc[i].dconv, C, go, w_a, w_b, w_h, w_stats, w_st1, w_st2, st));
             MI_STAGE("enc dconv done");
             mi_conv_desc r = base_desc(enc[i].rewrite, enc[i].ktab_rw, w_a, C * P, go);
-            r.epi = MI_EPI_GLU; r.y = w_skip[i]; r.y_bstride = C * P; r.y_cstride = P;
+            r.plain = 1; r.epi = MI_EPI_GLU; r.y = w_skip[i]; r.y_bstride = C * P; r.y_cstride = P;
             if (i == 0) { r.flags = MI_FLAG_EMB; r.emb = freq_emb; }
             MI_TRY(conv(r, st));
             xf = w_skip[i];
@@ -645,7 +659,7 @@ int Model::forward(const float *mix, float *out, int B, hipStream_t st) {
             MI_TRY(conv(d, st));
             MI_TRY(run_dconv(tenc[i].dconv, C, go, w_ta, w_tb, w_th, w_stats_t, w_st1_t, w_st2_t, st));
             mi_conv_desc r = base_desc(tenc[i].rewrite, tenc[i].ktab_rw, w_ta, C * P, go);
-            r.epi = MI_EPI_GLU; r.y = w_skip_t[i]; r.y_bstride = C * P; r.y_cstride = P;
+            r.plain = 1; r.epi = MI_EPI_GLU; r.y = w_skip_t[i]; r.y_bstride = C * P; r.y_cstride = P;
             MI_TRY(conv(r, st));
             xt = w_skip_t[i];
             MI_STAGE("tenc layer done");
@@ -657,7 +671,7 @@ int Model::forward(const float *mix, float *out, int B, hipStream_t st) {
         const int P = br ? Tt : Tf;
         const Geo g{B, 1, P, 0};
         mi_conv_desc d = base_desc(chan[br], chan_ktab[br], br ? xt : xf, (int64_t)384 * P, g);
-        d.epi = MI_EPI_LINEAR; d.y = w_tr_x1[br]; d.y_bstride = (int64_t)512 * P; d.y_cstride = P;
+        d.plain = 1; d.epi = MI_EPI_LINEAR; d.y = w_tr_x1[br]; d.y_bstride = (int64_t)512 * P; d.y_cstride = P;
         MI_TRY(conv(d, st));
         MI_TRY(launch_layernorm_cf(w_tr_x1[br], B, 512, P, norm_in_w[br], norm_in_b[br], pos_emb[br], w_tr_x[br][0], st));
     }
@@ -674,7 +688,7 @@ int Model::forward(const float *mix, float *out, int B, hipStream_t st) {
         const int P = br ? Tt : Tf;
         const Geo g{B, 1, P, 0};
         mi_conv_desc d = base_desc(chan[2 + br], chan_ktab[2 + br], w_tr_x[br][cur[br]], (int64_t)512 * P, g);
-        d.epi = MI_EPI_LINEAR; d.flags = MI_FLAG_RES; d.res = br ? w_skip_t[3] : w_skip[3];
+        d.plain = 1; d.epi = MI_EPI_LINEAR; d.flags = MI_FLAG_RES; d.res = br ? w_skip_t[3] : w_skip[3];
         d.y = br ? dtin : din; d.y_bstride = (int64_t)384 * P; d.y_cstride = P;
         MI_TRY(conv(d, st));
     }

@@ -125,6 +125,26 @@ __global__ __launch_bounds__(256) void gn_apply_cf_kernel(const float *__restric
     y[i] = (x[i] - s.x) * s.y * w[c] + bvec[c];
 }
 
+// x[b][c][d1][d2] <- gelu((x - mean[row]) * rstd[row] * w[c] + bias[c]) in place; row = b*D1 + d1 (row_mode 1) or b.
+// GroupNorm(1) + GELU of the DConv hidden tensor (demucs.py:139); Cs = channels allocated per item.  grid (ceil(D1*D2/256), C, B)
+__global__ __launch_bounds__(256) void gn_gelu_kernel(float *__restrict__ x, int C, int Cs, int D1, int D2, int row_mode,
+                                                      const float2 *__restrict__ st, const float *__restrict__ w,
+                                                      const float *__restrict__ bvec) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= D1 * D2) return;
+    const int c = blockIdx.y, b = blockIdx.z;
+    const float2 s = st[row_mode ? b * D1 + p / D2 : b];
+    const size_t i = ((size_t)b * Cs + c) * D1 * D2 + p;
+    x[i] = gelu_exact((x[i] - s.x) * s.y * w[c] + bvec[c]);
+}
+
+int launch_gn_gelu(float *x, int B, int C, int Cs, int D1, int D2, int row_mode, const float2 *stats, const float *w, const float *b,
+                   hipStream_t st) {
+    hipLaunchKernelGGL(gn_gelu_kernel, dim3(ceil_div((int64_t)D1 * D2, 256), C, B), dim3(256), 0, st, x, C, Cs, D1, D2, row_mode, stats, w, b);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+
 int launch_row_stats(const float *x, int rows, int64_t count, int64_t row_stride, double *stats, hipStream_t st) {
     MI_HIP(hipMemsetAsync(stats, 0, sizeof(double) * 2 * kStatSlots * rows, st));
     const int nblk = (int)std::min<int64_t>(256, (count + 4095) / 4096);

@@ -131,6 +131,11 @@ int mi_attention(const float *q_dev, const float *k_dev, const float *v_dev, flo
                  int32_t Tq, int32_t Tk, int64_t q_batch_stride, int64_t kv_batch_stride, int64_t o_batch_stride,
                  void *stream);
 
+/* In-place GroupNorm(1, C) + GELU of the first C channels of x (B, C_alloc, D1, D2) given per-row (mean, rstd) float2 statistics
+ *   (row = b*D1 + d1 if row_mode else b): the norm/activation pair inside DConv (demucs/demucs.py:139). */
+int mi_gn_gelu(float *x_dev, int32_t B, int32_t C, int32_t C_alloc, int32_t D1, int32_t D2, int32_t row_mode, const float *stats_dev,
+               const float *w_dev, const float *b_dev, void *stream);
+
 /* LayerNorm over the channel axis of channel-first tokens x (B, C, T), optional additive table
  *   add_dev (C, T) (nn.LayerNorm at demucs/transformer.py:434-436,591-592 + positional
  *   embedding add :655-663). */

@@ -132,7 +132,7 @@ def test_linear_scale_residual_big_k(lib):
     kt = ktab(K, 1, 1, 1, 1, 0, 0, Tn, Tn, Kpad)
     y = torch.empty(B, M, Tn, device="cuda")
     conv_call(wt=wt, M=M, Mpad=Mpad, K=K, Kpad=Kpad, ktab=kt, x=x.float().cuda(), x_bstride=K * Tn, B=B, D1=1, D2=Tn, O1=1, O2=Tn,
-              S1=1, S2=1, epi=EPI_LINEAR, flags=FLAG_SCALE | FLAG_RES, scale=pack_vec(g, Mpad), res=r.float().cuda(), bias=bias,
+              S1=1, S2=1, plain=1, epi=EPI_LINEAR, flags=FLAG_SCALE | FLAG_RES, scale=pack_vec(g, Mpad), res=r.float().cuda(), bias=bias,
               y=y, y_bstride=M * Tn, y_cstride=Tn, tile_m=tile)
     assert maxerr(y, want) < 6e-5
 
@@ -175,7 +175,7 @@ def test_conv_transpose_4phase(lib, freq):
 @pytest.mark.parametrize("freq", [True, False])
 def test_dconv_layer_three_passes(lib, freq):
     """One DConv residual layer (demucs.py:138-143,151-154): dilated conv3 + per-row statistics,
-    GroupNorm(1)+GELU prologue, 1x1 with statistics-only pass, then GroupNorm + GLU + LayerScale +
+    in-place GroupNorm(1)+GELU pass, 1x1 with statistics-only pass, then GroupNorm + GLU + LayerScale +
     residual epilogue.  Frequency branch rows are (b, fr); time branch rows are b."""
     C, h, dil = 48, 6, 2
     if freq:
@@ -221,9 +221,12 @@ def test_dconv_layer_three_passes(lib, freq):
     wt3, bias3, M3, Mpad3, K3, Kpad3, tile3 = pack_w(W3.reshape(2 * C, h), b3, glu=True)
     kt3 = ktab(h, 1, 1, 1, 1, 0, 0, P, D2, Kpad3)
     stats.zero_()
+    g1wd, g1bd = g1w.float().cuda(), g1b.float().cuda()
+    _lib.check(lib.mi_gn_gelu(hid.data_ptr(), B, h, h, D1, D2, row_mode, st1.data_ptr(), g1wd.data_ptr(), g1bd.data_ptr(), stream()),
+               "mi_gn_gelu")
+    torch.cuda.synchronize()
     common = dict(wt=wt3, M=M3, Mpad=Mpad3, K=K3, Kpad=Kpad3, ktab=kt3, x=hid, x_bstride=h * P, B=B, D1=D1, D2=D2, O1=D1, O2=D2,
-                  S1=1, S2=1, row_mode=row_mode, pro=1, pro_stats=st1, pro_w=g1w.float().cuda(), pro_b=g1b.float().cuda(),
-                  bias=bias3, tile_m=tile3)
+                  S1=1, S2=1, row_mode=row_mode, bias=bias3, tile_m=tile3, plain=1)
     conv_call(epi=EPI_STATS_ONLY, stats=stats, **common)
     s = stats.sum(1).cpu()
     cnt = 2 * C * (D2 if freq else P)
