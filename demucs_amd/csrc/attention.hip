@@ -44,37 +44,58 @@ __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict_
     for (int r = 0; r < 16; ++r) { oacc[0][r] = 0.f; oacc[1][r] = 0.f; }
     float mrun = -INFINITY, lrun = 0.f;     // running max (both halves agree) and this half's partial sum
 
-    for (int k0 = 0; k0 < Tk; k0 += KT) {
-        __syncthreads();                     // previous tile fully consumed
-        // stage K and V tiles: 64 rows x 64 keys each, float4 global loads
+    // global -> register staging of the next K/V tile (64 x 64 each): thread owns 4 float4 of each
+    const int sr = tid >> 4, sc4 = (tid & 15) * 4;            // rows sr + 16*it, columns sc4..sc4+3
+    float4 kst[4], vst[4];
+    auto stage_load = [&](int k0) {
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
-            const int idx = tid + 256 * it;  // 0..1023
-            const int r = idx >> 4, c4 = (idx & 15) * 4;
-            float4 kv4 = make_float4(0.f, 0.f, 0.f, 0.f), vv4 = kv4;
-            if (k0 + c4 + 3 < Tk) {
-                kv4 = *reinterpret_cast<const float4 *>(kp + (size_t)r * Tk + k0 + c4);
-                vv4 = *reinterpret_cast<const float4 *>(vp + (size_t)r * Tk + k0 + c4);
+            const int r = sr + 16 * it;
+            if (k0 + sc4 + 3 < Tk) {
+                kst[it] = *reinterpret_cast<const float4 *>(kp + (size_t)r * Tk + k0 + sc4);
+                vst[it] = *reinterpret_cast<const float4 *>(vp + (size_t)r * Tk + k0 + sc4);
             } else {
                 float tk[4] = {0, 0, 0, 0}, tv[4] = {0, 0, 0, 0};
                 for (int e = 0; e < 4; ++e)
-                    if (k0 + c4 + e < Tk) { tk[e] = kp[(size_t)r * Tk + k0 + c4 + e]; tv[e] = vp[(size_t)r * Tk + k0 + c4 + e]; }
-                kv4 = make_float4(tk[0], tk[1], tk[2], tk[3]); vv4 = make_float4(tv[0], tv[1], tv[2], tv[3]);
+                    if (k0 + sc4 + e < Tk) { tk[e] = kp[(size_t)r * Tk + k0 + sc4 + e]; tv[e] = vp[(size_t)r * Tk + k0 + sc4 + e]; }
+                kst[it] = make_float4(tk[0], tk[1], tk[2], tk[3]); vst[it] = make_float4(tv[0], tv[1], tv[2], tv[3]);
             }
-            *reinterpret_cast<float4 *>(&Ks[r][c4]) = kv4;
-            Vs[r][c4] = vv4.x; Vs[r][c4 + 1] = vv4.y; Vs[r][c4 + 2] = vv4.z; Vs[r][c4 + 3] = vv4.w;
+        }
+    };
+    stage_load(0);
+    for (int k0 = 0; k0 < Tk; k0 += KT) {
+        __syncthreads();                     // previous tile fully consumed
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int r = sr + 16 * it;
+            *reinterpret_cast<float4 *>(&Ks[r][sc4]) = kst[it];
+            Vs[r][sc4] = vst[it].x; Vs[r][sc4 + 1] = vst[it].y; Vs[r][sc4 + 2] = vst[it].z; Vs[r][sc4 + 3] = vst[it].w;
         }
         __syncthreads();
+        if (k0 + KT < Tk) stage_load(k0 + KT);   // in flight under this tile's 128 MFMAs
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
             const int kb = sub * 32;
-            // S^T[key][query]: A = K^T (lane: key li, k = d = 2s + lh), B = Q
+            // S^T[key][query]: A = K^T (lane: key li, k = d = 2s + lh), B = Q; fragments prefetched 4 deep
             f32x16 sacc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+            float kf[4];
 #pragma unroll
-            for (int s = 0; s < 32; ++s)
-                sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[2 * s + lh][kb + li], qreg[s], sacc, 0, 0, 0);
+            for (int s = 0; s < 4; ++s) kf[s] = Ks[2 * s + lh][kb + li];
+#pragma unroll
+            for (int s = 0; s < 32; ++s) {
+                const float a = kf[s & 3];
+                if (s + 4 < 32) kf[s & 3] = Ks[2 * (s + 4) + lh][kb + li];
+                sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, qreg[s], sacc, 0, 0, 0);
+            }
+            // first V fragments can already be fetched while the softmax runs
+            float vf0[4], vf1[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int kc = kb + (s & 3) + 8 * (s >> 2) + 4 * lh;
+                vf0[s] = Vs[li][kc]; vf1[s] = Vs[32 + li][kc];
+            }
             // register r of lane (li, lh) is key kb + (r&3) + 8(r>>2) + 4 lh, query li
             float mloc = -INFINITY;
 #pragma unroll
@@ -100,9 +121,13 @@ __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict_
             // O^T[d][query] += V[d][key] P^T[key][query]: A = V (lane: d = dt*32 + li, k = key(s, lh)), B = P regs
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
-                const int kc = kb + (s & 3) + 8 * (s >> 2) + 4 * lh;
-                oacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[li][kc], sacc[s], oacc[0], 0, 0, 0);
-                oacc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[32 + li][kc], sacc[s], oacc[1], 0, 0, 0);
+                const float a0 = vf0[s & 3], a1 = vf1[s & 3];
+                if (s + 4 < 16) {
+                    const int kc = kb + ((s + 4) & 3) + 8 * ((s + 4) >> 2) + 4 * lh;
+                    vf0[s & 3] = Vs[li][kc]; vf1[s & 3] = Vs[32 + li][kc];
+                }
+                oacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, sacc[s], oacc[0], 0, 0, 0);
+                oacc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, sacc[s], oacc[1], 0, 0, 0);
             }
         }
     }
