@@ -65,6 +65,7 @@ typedef struct mi_conv_desc {
     int32_t plain;          /* 1: the gather is the identity over input channels (1x1 conv / linear with channel
                                stride O1*O2): enables the table-free float4 loader when shapes allow             */
     int32_t reserved;
+    float *sink;            /* >= 256 floats that out-of-range epilogue stores are diverted to; NULL = library-owned */
 } mi_conv_desc;
 
 #ifdef __cplusplus

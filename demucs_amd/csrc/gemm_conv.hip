@@ -33,6 +33,16 @@ __device__ __forceinline__ ColInfo decompose(int n, int N, int P, int O2) {
     return c;
 }
 
+// the 16 rows a lane owns in one 32x32 accumulator tile are 4 groups of 4 consecutive rows: fetch a per-row
+// vector (bias, scale, GroupNorm affine) for them with 4 float4 loads instead of 16 dependent dword loads
+__device__ __forceinline__ void load_rows16(const float *p, int mbase, float (&out)[16]) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float4 v = *reinterpret_cast<const float4 *>(p + mbase + 8 * g);
+        out[4 * g] = v.x; out[4 * g + 1] = v.y; out[4 * g + 2] = v.z; out[4 * g + 3] = v.w;
+    }
+}
+
 // B-operand gather for one element: branch-free (invalid taps read x[0] and are zeroed by a select)
 __device__ __forceinline__ float gather_b(const mi_conv_desc &d, const mi_ktab_entry e, const float *xcol, int i1b, int i2b,
                                           bool colvalid, bool &ok) {
@@ -43,7 +53,9 @@ __device__ __forceinline__ float gather_b(const mi_conv_desc &d, const mi_ktab_e
 }
 
 // PLAIN = 1x1 / linear layer with K % 16 == 0 and (O1*O2) % 4 == 0: no gather table, float4 activation loads.
-template <int WM, int WN, int TM, int TN, int EPI, bool PLAIN>
+// LFLAGS: the MI_FLAG_GELU/SCALE/RES bits of a LINEAR epilogue as compile-time constants (runtime flag branches
+// inside the unrolled epilogue made hipcc copy all 64 accumulators to VGPRs at once: 204 registers, 2 waves/SIMD)
+template <int WM, int WN, int TM, int TN, int EPI, int LFLAGS, bool PLAIN>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const mi_conv_desc d, const int N, const int MT) {
     constexpr int BM = WM * TM * 32;
     static_assert(WN * TN * 32 == BN, "block N tile is 128");
@@ -152,6 +164,15 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const mi_conv_desc d, co
                 for (int b = 0; b < TN; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s & 1][a], bf[s & 1][b], acc[a][b], 0, 0, 0);
         }
+        // pin the software pipeline: the LDS reads of step s+1 issue BEFORE the MFMAs of step s, so their
+        // latency hides under the matrix pipe (hipcc otherwise sinks each read next to its use and waits)
+        constexpr int kReads = (TM == 2 ? 1 : TM) + (TN == 2 ? 1 : TN);    // ds_read2_b32 pairs two 32-apart tiles
+        __builtin_amdgcn_sched_group_barrier(0x100, kReads, 0);
+#pragma unroll
+        for (int s = 0; s < BK / 2; ++s) {
+            if (s + 1 < BK / 2) __builtin_amdgcn_sched_group_barrier(0x100, kReads, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
+        }
         if (kt + 1 < nk) MI_STORE_TILE(cur ^ 1);
         __syncthreads();
         cur ^= 1;
@@ -162,6 +183,15 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const mi_conv_desc d, co
     // ---- epilogue ---------------------------------------------------------------------------------
     // acc[a][b][r] is C[m][n] with n = ncol(b) + li, m = mrow(a) + (r & 3) + 8 * (r >> 2) + 4 * lh
     const int slot = blockIdx.x % kStatSlots;
+    float *const sink = d.sink + tid;
+    float biasr[TM][16], auxr[TM][16], aux2r[TM][16];
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+        const int mb = m0 + (wm * TM + a) * 32 + 4 * lh;
+        load_rows16(d.bias, mb, biasr[a]);
+        if (EPI == MI_EPI_LINEAR && (LFLAGS & MI_FLAG_SCALE)) load_rows16(d.scale, mb, auxr[a]);
+        if (EPI == MI_EPI_GN_GLU) { load_rows16(d.gn_w, mb, auxr[a]); load_rows16(d.gn_b, mb, aux2r[a]); }
+    }
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
         const int n = n0 + (wn * TN + b) * 32 + li;
@@ -175,63 +205,66 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const mi_conv_desc d, co
         }
 #pragma unroll
         for (int a = 0; a < TM; ++a) {
+            // keep the epilogue of one 32x32 accumulator tile together: without the fence hipcc copies all
+            // accumulators out of the AGPR file first and the VGPR allocation (not the main loop) caps occupancy
+            __builtin_amdgcn_sched_barrier(0);
             const int mbase = m0 + (wm * TM + a) * 32 + 4 * lh;
             if (EPI == MI_EPI_LINEAR) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
+                    if ((r & 3) == 0) __builtin_amdgcn_sched_barrier(0);   // 4 values in flight, not 64 (GELU temporaries)
                     const int m = mbase + (r & 3) + 8 * (r >> 2);
-                    float v = acc[a][b][r] + d.bias[m];
-                    if (d.flags & MI_FLAG_GELU) v = gelu_exact(v);
-                    if (d.flags & MI_FLAG_SCALE) v *= d.scale[m];
-                    if (c.valid && m < d.M) {
-                        const size_t idx = (size_t)c.b * d.y_bstride + (size_t)m * d.y_cstride + c.p;
-                        if (d.flags & MI_FLAG_RES) v += d.res[idx];
-                        d.y[idx] = v;
-                    }
+                    float v = acc[a][b][r] + biasr[a][r];
+                    if (LFLAGS & MI_FLAG_GELU) v = gelu_exact(v);
+                    if (LFLAGS & MI_FLAG_SCALE) v *= auxr[a][r];
+                    // branch-free: out-of-range rows / columns are stored to a per-lane sink word, so the
+                    // epilogue stays one basic block and accumulators leave the AGPR file a few at a time
+                    const bool ok = c.valid && m < d.M;
+                    const size_t idx = ok ? (size_t)c.b * d.y_bstride + (size_t)m * d.y_cstride + c.p : 0;
+                    if (LFLAGS & MI_FLAG_RES) v += d.res[idx];
+                    *(ok ? d.y + idx : sink) = v;
                 }
             } else if (EPI == MI_EPI_GLU || EPI == MI_EPI_GN_GLU) {
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
                     const int m = mbase + (r & 3) + 8 * (r >> 2);   // even row: value, m+1: gate
-                    float va = acc[a][b][r] + d.bias[m], vg = acc[a][b][r + 1] + d.bias[m + 1];
+                    float va = acc[a][b][r] + biasr[a][r], vg = acc[a][b][r + 1] + biasr[a][r + 1];
                     if (EPI == MI_EPI_GN_GLU) {
-                        va = (va - gmean) * grstd * d.gn_w[m] + d.gn_b[m];
-                        vg = (vg - gmean) * grstd * d.gn_w[m + 1] + d.gn_b[m + 1];
+                        va = (va - gmean) * grstd * auxr[a][r] + aux2r[a][r];
+                        vg = (vg - gmean) * grstd * auxr[a][r + 1] + aux2r[a][r + 1];
                     }
                     float v = va * sigmoid_f(vg);
                     const int ch = m >> 1;
-                    if (c.valid && m < d.M) {
-                        const size_t idx = (size_t)c.b * d.y_bstride + (size_t)ch * d.y_cstride + c.p;
-                        if (EPI == MI_EPI_GN_GLU) v = d.res[idx] + d.scale[ch] * v;
-                        else if (d.flags & MI_FLAG_EMB) v += d.emb[ch * d.O1 + c.o1];
-                        d.y[idx] = v;
-                    }
+                    const bool ok = c.valid && m < d.M;
+                    const size_t idx = ok ? (size_t)c.b * d.y_bstride + (size_t)ch * d.y_cstride + c.p : 0;
+                    if (EPI == MI_EPI_GN_GLU) v = d.res[idx] + d.scale[ok ? ch : 0] * v;
+                    else if (d.flags & MI_FLAG_EMB) v += d.emb[ok ? ch * d.O1 + c.o1 : 0];
+                    *(ok ? d.y + idx : sink) = v;
                 }
             } else if (EPI == MI_EPI_BIAS_STATS || EPI == MI_EPI_STATS_ONLY) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
+                    if ((r & 3) == 0) __builtin_amdgcn_sched_barrier(0);
                     const int m = mbase + (r & 3) + 8 * (r >> 2);
-                    const float v = acc[a][b][r] + d.bias[m];
-                    if (c.valid && m < d.M) {
-                        if (EPI == MI_EPI_BIAS_STATS)
-                            d.y[(size_t)c.b * d.y_bstride + (size_t)m * d.y_cstride + c.p] = v;
-                        s1 += v; s2 += v * v;
-                    }
+                    const float v = acc[a][b][r] + biasr[a][r];
+                    const bool ok = c.valid && m < d.M;
+                    if (EPI == MI_EPI_BIAS_STATS)
+                        *(ok ? d.y + ((size_t)c.b * d.y_bstride + (size_t)m * d.y_cstride + c.p) : sink) = v;
+                    s1 += ok ? v : 0.f; s2 += ok ? v * v : 0.f;
                 }
             } else if (EPI == MI_EPI_CONVTR) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int m = mbase + (r & 3) + 8 * (r >> 2);
                     const int co = m >> 2, ph = m & 3;
-                    float v = acc[a][b][r] + d.bias[m];
+                    float v = acc[a][b][r] + biasr[a][r];
                     if (d.flags & MI_FLAG_GELU) v = gelu_exact(v);
                     const int o = 4 * ((d.flags & MI_FLAG_TR_FREQ) ? c.o1 : c.o2) + ph - 2;
-                    if (c.valid && m < d.M && o >= 0 && o < d.out_len) {
-                        const size_t pos = (d.flags & MI_FLAG_TR_FREQ) ? (size_t)o * d.O2 + c.o2 : (size_t)o;
-                        const size_t idx = (size_t)c.b * d.y_bstride + (size_t)co * d.y_cstride + pos;
-                        if (d.flags & MI_FLAG_RES) v += d.res[idx];
-                        d.y[idx] = v;
-                    }
+                    const bool ok = c.valid && m < d.M && o >= 0 && o < d.out_len;
+                    const size_t pos = (d.flags & MI_FLAG_TR_FREQ) ? (size_t)o * d.O2 + c.o2 : (size_t)o;
+                    const size_t idx = ok ? (size_t)c.b * d.y_bstride + (size_t)co * d.y_cstride + pos : 0;
+                    if (d.flags & MI_FLAG_RES) v += d.res[idx];
+                    *(ok ? d.y + idx : sink) = v;
                 }
             }
         }
@@ -263,25 +296,25 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const mi_conv_desc d, co
 }
 
 // ---------------------------------------------------------------------------------------------
-template <int WM, int WN, int TM, int TN, int EPI, bool PLAIN>
+template <int WM, int WN, int TM, int TN, int EPI, int LFLAGS, bool PLAIN>
 static int launch_cfg(const mi_conv_desc &d, hipStream_t st) {
     constexpr int BM = WM * TM * 32;
     const int64_t N64 = (int64_t)d.B * d.O1 * d.O2;
     MI_REQUIRE(N64 < (1ll << 31) - 256, "conv: too many output positions (%lld)", (long long)N64);
     MI_REQUIRE(d.Mpad % BM == 0, "conv: Mpad %d not a multiple of the %d-row tile", d.Mpad, BM);
     const int N = (int)N64, MT = d.Mpad / BM, NT = ceil_div(N, BN);
-    hipLaunchKernelGGL((conv_gemm_kernel<WM, WN, TM, TN, EPI, PLAIN>), dim3((unsigned)MT * NT), dim3(256), 0, st, d, N, MT);
+    hipLaunchKernelGGL((conv_gemm_kernel<WM, WN, TM, TN, EPI, LFLAGS, PLAIN>), dim3((unsigned)MT * NT), dim3(256), 0, st, d, N, MT);
     MI_CHECK_LAUNCH();
     return MI_OK;
 }
 
-template <int EPI, bool PLAIN>
+template <int EPI, int LFLAGS, bool PLAIN>
 static int launch_tile(const mi_conv_desc &d, int tile, hipStream_t st) {
     switch (tile) {
-        case 128: return launch_cfg<2, 2, 2, 2, EPI, PLAIN>(d, st);
-        case 96: return launch_cfg<1, 4, 3, 1, EPI, PLAIN>(d, st);
-        case 64: return launch_cfg<1, 4, 2, 1, EPI, PLAIN>(d, st);
-        case 32: return launch_cfg<1, 4, 1, 1, EPI, PLAIN>(d, st);
+        case 128: return launch_cfg<2, 2, 2, 2, EPI, LFLAGS, PLAIN>(d, st);
+        case 96: return launch_cfg<1, 4, 3, 1, EPI, LFLAGS, PLAIN>(d, st);
+        case 64: return launch_cfg<1, 4, 2, 1, EPI, LFLAGS, PLAIN>(d, st);
+        case 32: return launch_cfg<1, 4, 1, 1, EPI, LFLAGS, PLAIN>(d, st);
     }
     return set_error(MI_EINVAL, "conv: unsupported tile_m %d", tile);
 }
@@ -295,7 +328,17 @@ int conv_pick_tile(int M) {
     return 128;
 }
 
-int launch_conv(const mi_conv_desc &d, hipStream_t st) {
+// 256-float dump for the epilogue's out-of-range stores (one word per thread), shared by all launches
+static float *conv_sink() {
+    static float *p = nullptr;
+    if (!p && hipMalloc((void **)&p, 256 * sizeof(float)) != hipSuccess) p = nullptr;
+    return p;
+}
+
+int launch_conv(const mi_conv_desc &din, hipStream_t st) {
+    mi_conv_desc d = din;
+    if (!d.sink) d.sink = conv_sink();
+    MI_REQUIRE(d.sink, "conv: could not allocate the store sink");
     MI_REQUIRE(d.Kpad % BK == 0 && d.Kpad >= BK, "conv: Kpad %d must be a positive multiple of %d", d.Kpad, BK);
     MI_REQUIRE(d.Mpad % 4 == 0, "conv: Mpad %d must be a multiple of 4", d.Mpad);
     MI_REQUIRE(d.O2 >= 32 || d.row_mode == 0 || (d.epi != MI_EPI_BIAS_STATS && d.epi != MI_EPI_STATS_ONLY),
@@ -307,9 +350,20 @@ int launch_conv(const mi_conv_desc &d, hipStream_t st) {
     const bool plain = d.plain && d.K == d.Kpad && P % 4 == 0 && d.x_bstride % 4 == 0 && ((uintptr_t)d.x & 15) == 0 &&
                        d.S1 == 1 && d.S2 == 1 && d.D1 == d.O1 && d.D2 == d.O2;
 #define MI_DISPATCH(E)                                              \
-    case E: return plain ? launch_tile<E, true>(d, tile, st) : launch_tile<E, false>(d, tile, st)
+    case E: return plain ? launch_tile<E, 0, true>(d, tile, st) : launch_tile<E, 0, false>(d, tile, st)
+#define MI_LINEAR(F)                                                \
+    case F: return plain ? launch_tile<MI_EPI_LINEAR, F, true>(d, tile, st) : launch_tile<MI_EPI_LINEAR, F, false>(d, tile, st)
+    if (d.epi == MI_EPI_LINEAR) {
+        switch (d.flags & (MI_FLAG_GELU | MI_FLAG_SCALE | MI_FLAG_RES)) {
+            MI_LINEAR(0);
+            MI_LINEAR(MI_FLAG_GELU);
+            MI_LINEAR(MI_FLAG_RES);
+            MI_LINEAR(MI_FLAG_SCALE | MI_FLAG_RES);
+        }
+        return set_error(MI_EINVAL, "conv: unsupported LINEAR flag combination %d", d.flags);
+    }
+#undef MI_LINEAR
     switch (d.epi) {
-        MI_DISPATCH(MI_EPI_LINEAR);
         MI_DISPATCH(MI_EPI_GLU);
         MI_DISPATCH(MI_EPI_BIAS_STATS);
         MI_DISPATCH(MI_EPI_STATS_ONLY);
