@@ -56,7 +56,7 @@ __device__ __forceinline__ float gather_b(const mi_conv_desc &d, const mi_ktab_e
 // LFLAGS: the MI_FLAG_GELU/SCALE/RES bits of a LINEAR epilogue as compile-time constants (runtime flag branches
 // inside the unrolled epilogue made hipcc copy all 64 accumulators to VGPRs at once: 204 registers, 2 waves/SIMD)
 template <int WM, int WN, int TM, int TN, int EPI, int LFLAGS, bool PLAIN>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(const mi_conv_desc d, const int N, const int MT) {
+__global__ __launch_bounds__(256, (TM * TN == 4 ? 3 : 4)) void conv_gemm_kernel(const mi_conv_desc d, const int N, const int MT) {
     constexpr int BM = WM * TM * 32;
     static_assert(WN * TN * 32 == BN, "block N tile is 128");
     static_assert(WM * WN == 4, "4 waves");
@@ -184,14 +184,6 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const mi_conv_desc d, co
     // acc[a][b][r] is C[m][n] with n = ncol(b) + li, m = mrow(a) + (r & 3) + 8 * (r >> 2) + 4 * lh
     const int slot = blockIdx.x % kStatSlots;
     float *const sink = d.sink + tid;
-    float biasr[TM][16], auxr[TM][16], aux2r[TM][16];
-#pragma unroll
-    for (int a = 0; a < TM; ++a) {
-        const int mb = m0 + (wm * TM + a) * 32 + 4 * lh;
-        load_rows16(d.bias, mb, biasr[a]);
-        if (EPI == MI_EPI_LINEAR && (LFLAGS & MI_FLAG_SCALE)) load_rows16(d.scale, mb, auxr[a]);
-        if (EPI == MI_EPI_GN_GLU) { load_rows16(d.gn_w, mb, auxr[a]); load_rows16(d.gn_b, mb, aux2r[a]); }
-    }
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
         const int n = n0 + (wn * TN + b) * 32 + li;
@@ -209,14 +201,18 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const mi_conv_desc d, co
             // accumulators out of the AGPR file first and the VGPR allocation (not the main loop) caps occupancy
             __builtin_amdgcn_sched_barrier(0);
             const int mbase = m0 + (wm * TM + a) * 32 + 4 * lh;
+            float biasr[16], auxr[16], aux2r[16];        // this tile's per-row vectors (float4 loads, L1/L2 hits)
+            load_rows16(d.bias, mbase, biasr);
+            if (EPI == MI_EPI_LINEAR && (LFLAGS & MI_FLAG_SCALE)) load_rows16(d.scale, mbase, auxr);
+            if (EPI == MI_EPI_GN_GLU) { load_rows16(d.gn_w, mbase, auxr); load_rows16(d.gn_b, mbase, aux2r); }
             if (EPI == MI_EPI_LINEAR) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     if ((r & 3) == 0) __builtin_amdgcn_sched_barrier(0);   // 4 values in flight, not 64 (GELU temporaries)
                     const int m = mbase + (r & 3) + 8 * (r >> 2);
-                    float v = acc[a][b][r] + biasr[a][r];
+                    float v = acc[a][b][r] + biasr[r];
                     if (LFLAGS & MI_FLAG_GELU) v = gelu_exact(v);
-                    if (LFLAGS & MI_FLAG_SCALE) v *= auxr[a][r];
+                    if (LFLAGS & MI_FLAG_SCALE) v *= auxr[r];
                     // branch-free: out-of-range rows / columns are stored to a per-lane sink word, so the
                     // epilogue stays one basic block and accumulators leave the AGPR file a few at a time
                     const bool ok = c.valid && m < d.M;
@@ -228,10 +224,10 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const mi_conv_desc d, co
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
                     const int m = mbase + (r & 3) + 8 * (r >> 2);   // even row: value, m+1: gate
-                    float va = acc[a][b][r] + biasr[a][r], vg = acc[a][b][r + 1] + biasr[a][r + 1];
+                    float va = acc[a][b][r] + biasr[r], vg = acc[a][b][r + 1] + biasr[r + 1];
                     if (EPI == MI_EPI_GN_GLU) {
-                        va = (va - gmean) * grstd * auxr[a][r] + aux2r[a][r];
-                        vg = (vg - gmean) * grstd * auxr[a][r + 1] + aux2r[a][r + 1];
+                        va = (va - gmean) * grstd * auxr[r] + aux2r[r];
+                        vg = (vg - gmean) * grstd * auxr[r + 1] + aux2r[r + 1];
                     }
                     float v = va * sigmoid_f(vg);
                     const int ch = m >> 1;
@@ -246,7 +242,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const mi_conv_desc d, co
                 for (int r = 0; r < 16; ++r) {
                     if ((r & 3) == 0) __builtin_amdgcn_sched_barrier(0);
                     const int m = mbase + (r & 3) + 8 * (r >> 2);
-                    const float v = acc[a][b][r] + biasr[a][r];
+                    const float v = acc[a][b][r] + biasr[r];
                     const bool ok = c.valid && m < d.M;
                     if (EPI == MI_EPI_BIAS_STATS)
                         *(ok ? d.y + ((size_t)c.b * d.y_bstride + (size_t)m * d.y_cstride + c.p) : sink) = v;
@@ -257,7 +253,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const mi_conv_desc d, co
                 for (int r = 0; r < 16; ++r) {
                     const int m = mbase + (r & 3) + 8 * (r >> 2);
                     const int co = m >> 2, ph = m & 3;
-                    float v = acc[a][b][r] + biasr[a][r];
+                    float v = acc[a][b][r] + biasr[r];
                     if (d.flags & MI_FLAG_GELU) v = gelu_exact(v);
                     const int o = 4 * ((d.flags & MI_FLAG_TR_FREQ) ? c.o1 : c.o2) + ph - 2;
                     const bool ok = c.valid && m < d.M && o >= 0 && o < d.out_len;
