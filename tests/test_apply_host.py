@@ -168,3 +168,28 @@ def test_engine_model_has_no_cpu_path():
         m.load_state_dict({"encoder.0.conv.weight": torch.zeros(1)})
     with pytest.raises(ValueError):
         HTDemucs(cfg.sources, depth=6)
+
+
+def test_separator_tensor_contract():
+    """api.py:265-291: normalise by the mono mean/std in place, separate, restore the input."""
+    from demucs_amd.api import LoadModelError, Separator
+    wav = torch.randn(2, 900, generator=torch.Generator().manual_seed(8)) * 3 + 0.5
+    wav0 = wav.clone()
+    events = []
+    sep = Separator(ToyModel(), device="cpu", shifts=0, callback=lambda d: events.append(d), callback_arg={"tag": 1})
+    got_wav, stems = sep.separate_tensor(wav)
+    assert got_wav is wav and torch.allclose(wav, wav0, atol=1e-6)
+    assert list(stems) == ["a", "b", "c"] and stems["a"].shape == (2, 900)
+    ref = wav0.mean(0)
+    norm = (wav0 - ref.mean()) / (ref.std() + 1e-8)
+    want = A.apply_model(ToyModel(), norm[None], shifts=0) * (ref.std() + 1e-8) + ref.mean()
+    assert torch.allclose(torch.stack(list(stems.values())), want[0], atol=1e-6)
+    assert events and events[0]["audio_length"] == 900 and events[0]["tag"] == 1
+    assert sep.samplerate == 100 and sep.audio_channels == 2 and sep.model is not None
+    sep.update_parameter(segment=None, shifts=1)
+    with pytest.raises(ValueError):
+        sep.update_parameter(segment=0)
+    with pytest.raises(NotImplementedError):
+        sep.separate_tensor(wav, sr=48000)
+    with pytest.raises(LoadModelError):
+        Separator("htdemucs")
