@@ -207,7 +207,7 @@ int mi_gn_gelu(float *x_dev, int32_t B, int32_t C, int32_t C_alloc, int32_t D1, 
 int mi_layernorm_cf(const float *x_dev, int32_t B, int32_t C, int32_t T, const float *w_dev, const float *b_dev,
                     const float *add_dev, float *y_dev, void *stream) {
     MI_REQUIRE(x_dev && w_dev && b_dev && y_dev, "mi_layernorm_cf: null argument");
-    return launch_layernorm_cf(x_dev, B, C, T, w_dev, b_dev, add_dev, y_dev, (hipStream_t)stream);
+    return launch_layernorm_cf(x_dev, B, C, T, w_dev, b_dev, add_dev, y_dev, nullptr, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -27,6 +27,11 @@ enum mi_epilogue {
 #define MI_FLAG_RES 4
 #define MI_FLAG_EMB 8
 #define MI_FLAG_TR_FREQ 16 /* CONVTR scatters along o1 (frequency axis) instead of o2 (time axis) */
+/* LINEAR on LayerNorm-ed tokens without materialising them: with W' = W diag(ln_w), the caller packs W' as
+ * the weights, c1[m] = sum_k W'[m][k] in `scale`, c2[m] = (W ln_b)[m] + bias[m] in `bias`, and passes the
+ * per-column (mean, rstd) of the RAW input in `pro_stats` (float2 per output column):
+ *     y = act( rstd[n] * (acc - mean[n] * c1[m]) + c2[m] )                                      */
+#define MI_FLAG_LN 32
 
 typedef struct mi_ktab_entry {
     int32_t off; /* element offset added to the column base: ci*chan_stride + d1*D2 + d2 */

@@ -190,6 +190,9 @@ __global__ __launch_bounds__(256, (TM * TN == 4 ? 3 : 4)) void conv_gemm_kernel(
         const ColInfo c = decompose(n, N, P, d.O2);
         const int row = d.row_mode ? c.b * d.O1 + c.o1 : c.b;
         float s1 = 0.f, s2 = 0.f;
+        float2 lnstat = make_float2(0.f, 1.f);
+        if (EPI == MI_EPI_LINEAR && (LFLAGS & MI_FLAG_LN))
+            lnstat = reinterpret_cast<const float2 *>(d.pro_stats)[c.valid ? n : 0];
         float gmean = 0.f, grstd = 0.f;
         if (EPI == MI_EPI_GN_GLU) {
             const float2 st = reinterpret_cast<const float2 *>(d.gn_stats)[row];
@@ -203,14 +206,16 @@ __global__ __launch_bounds__(256, (TM * TN == 4 ? 3 : 4)) void conv_gemm_kernel(
             const int mbase = m0 + (wm * TM + a) * 32 + 4 * lh;
             float biasr[16], auxr[16], aux2r[16];        // this tile's per-row vectors (float4 loads, L1/L2 hits)
             load_rows16(d.bias, mbase, biasr);
-            if (EPI == MI_EPI_LINEAR && (LFLAGS & MI_FLAG_SCALE)) load_rows16(d.scale, mbase, auxr);
+            if (EPI == MI_EPI_LINEAR && (LFLAGS & (MI_FLAG_SCALE | MI_FLAG_LN))) load_rows16(d.scale, mbase, auxr);
             if (EPI == MI_EPI_GN_GLU) { load_rows16(d.gn_w, mbase, auxr); load_rows16(d.gn_b, mbase, aux2r); }
             if (EPI == MI_EPI_LINEAR) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     if ((r & 3) == 0) __builtin_amdgcn_sched_barrier(0);   // 4 values in flight, not 64 (GELU temporaries)
                     const int m = mbase + (r & 3) + 8 * (r >> 2);
-                    float v = acc[a][b][r] + biasr[r];
+                    float v;
+                    if (LFLAGS & MI_FLAG_LN) v = lnstat.y * (acc[a][b][r] - lnstat.x * auxr[r]) + biasr[r];
+                    else v = acc[a][b][r] + biasr[r];
                     if (LFLAGS & MI_FLAG_GELU) v = gelu_exact(v);
                     if (LFLAGS & MI_FLAG_SCALE) v *= auxr[r];
                     // branch-free: out-of-range rows / columns are stored to a per-lane sink word, so the
@@ -341,6 +346,7 @@ int launch_conv(const mi_conv_desc &din, hipStream_t st) {
                "conv: statistics epilogue needs O2 >= 32");
     const int tile = d.tile_m ? d.tile_m : conv_pick_tile(d.M);
     MI_REQUIRE(d.pro == 0, "conv: the fused GroupNorm+GELU prologue was replaced by launch_gn_gelu");
+    MI_REQUIRE(!(d.flags & MI_FLAG_LN) || (d.pro_stats && d.scale && d.epi == MI_EPI_LINEAR), "conv: MI_FLAG_LN needs pro_stats and scale");
     // plain fast path: a 1x1 / linear layer whose gather is the identity
     const int64_t P = (int64_t)d.O1 * d.O2;
     const bool plain = d.plain && d.K == d.Kpad && P % 4 == 0 && d.x_bstride % 4 == 0 && ((uintptr_t)d.x & 15) == 0 &&
@@ -350,11 +356,13 @@ int launch_conv(const mi_conv_desc &din, hipStream_t st) {
 #define MI_LINEAR(F)                                                \
     case F: return plain ? launch_tile<MI_EPI_LINEAR, F, true>(d, tile, st) : launch_tile<MI_EPI_LINEAR, F, false>(d, tile, st)
     if (d.epi == MI_EPI_LINEAR) {
-        switch (d.flags & (MI_FLAG_GELU | MI_FLAG_SCALE | MI_FLAG_RES)) {
+        switch (d.flags & (MI_FLAG_GELU | MI_FLAG_SCALE | MI_FLAG_RES | MI_FLAG_LN)) {
             MI_LINEAR(0);
             MI_LINEAR(MI_FLAG_GELU);
             MI_LINEAR(MI_FLAG_RES);
             MI_LINEAR(MI_FLAG_SCALE | MI_FLAG_RES);
+            MI_LINEAR(MI_FLAG_LN);
+            MI_LINEAR(MI_FLAG_LN | MI_FLAG_GELU);
         }
         return set_error(MI_EINVAL, "conv: unsupported LINEAR flag combination %d", d.flags);
     }

@@ -25,7 +25,10 @@ int launch_finalize_stats(const double *stats, int rows, double count, float eps
                           hipStream_t st);
 int launch_row_affine(const float *x, int rows, int64_t count, const float2 *norm, float *y, hipStream_t st);
 int launch_layernorm_cf(const float *x, int B, int C, int T, const float *w, const float *b, const float *pe, float *y,
-                        hipStream_t st);
+                        float2 *ostat, hipStream_t st);
+int launch_token_stats(const float *x, int B, int C, int T, float2 *ostat, hipStream_t st);
+int launch_gn_apply_tokstats(const float *x, int B, int C, int T, const float2 *gstat, const float *w, const float *b, float *y,
+                             float2 *ostat, hipStream_t st);
 int launch_gn_apply_cf(const float *x, int B, int C, int T, const float2 *stats, const float *w, const float *b, float *y,
                        hipStream_t st);
 

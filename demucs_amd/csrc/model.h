@@ -37,6 +37,8 @@ struct DecW {
 };
 struct TrLayerW {
     PackedConv qkv_proj, q_proj, kv_proj, out_proj, lin1, lin2;
+    // LayerNorm folded into the projection that consumes it: c1[m] = sum_k (W diag(ln_w))[m][k] (see MI_FLAG_LN)
+    float *qkv_c1 = nullptr, *q_c1 = nullptr, *kv_c1 = nullptr, *lin1_c1 = nullptr;
     float *norm_w[4] = {}, *norm_b[4] = {};   // norm1, norm2, norm3 (cross only), norm_out
     float *gamma1 = nullptr, *gamma2 = nullptr;
 };
@@ -85,6 +87,7 @@ struct Model {
     float *w_skip[4] = {}, *w_skip_t[4] = {};
     float *w_a = nullptr, *w_b = nullptr, *w_c = nullptr, *w_h = nullptr;
     float *w_ta = nullptr, *w_tb = nullptr, *w_tc = nullptr, *w_th = nullptr;
+    float2 *w_tr_stat[2][2] = {}, *w_tr_stat1[2] = {};   // per-token (mean, rstd) of the layer inputs / of x1
     float *w_tr_x[2][2] = {}, *w_tr_ln[2] = {}, *w_tr_ln2[2] = {}, *w_tr_qkv[2] = {}, *w_tr_att[2] = {}, *w_tr_x1[2] = {},
           *w_tr_x2[2] = {}, *w_tr_ffh[2] = {};
     float *w_yspec = nullptr, *w_ytime = nullptr, *w_yt = nullptr, *w_fr = nullptr;
@@ -102,12 +105,15 @@ struct Model {
     int pack_conv(const float *W, const float *bias, int M, int K, bool glu, PackedConv *pc);
     int pack_convtr(const float *W, const float *bias, int Cin, int Cout, PackedConv *pc);
     int pack_vec(const float *v, int n, int npad, bool glu, float **out);
+    int pack_linear_ln(const float *W, const float *bias, const float *ln_w, const float *ln_b, int M, int K, PackedConv *pc,
+                       float **c1);
     int make_ktab(const Gather &g, int Kpad, mi_ktab_entry **out);
     int load_dconv(const WeightTable &wt, const std::string &prefix, int C, int64_t chan_stride, int D2, DConvW *dw);
     int alloc_workspace();
     int run_dconv(const DConvW &w, int C, const Geo &g, float *x, float *tmp, float *hidden, double *stats, float2 *st1, float2 *st2,
                   hipStream_t st);
-    int run_tr_layer(int br, int k, int B, const float *x, const float *other, float *out, hipStream_t st);
+    int run_tr_layer(int br, int k, int B, const float *x, const float2 *xstat, const float *other, const float2 *ostat, float *out,
+                     float2 *outstat, hipStream_t st);
 };
 
 }  // namespace mi

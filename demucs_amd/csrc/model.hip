@@ -199,6 +199,24 @@ int Model::pack_convtr(const float *W, const float *bias, int Cin, int Cout, Pac
     return MI_OK;
 }
 
+// Linear layer applied to LayerNorm(x): fold the LayerNorm affine into the weights (MI_FLAG_LN in gemm_conv.h)
+int Model::pack_linear_ln(const float *W, const float *bias, const float *ln_w, const float *ln_b, int M, int K, PackedConv *pc,
+                          float **c1) {
+    std::vector<float> wf((size_t)M * K), c2(M), c1h(M);
+    for (int m = 0; m < M; ++m) {
+        double s1 = 0.0, s2 = bias ? (double)bias[m] : 0.0;
+        for (int k = 0; k < K; ++k) {
+            const float wp = W[(size_t)m * K + k] * ln_w[k];
+            wf[(size_t)m * K + k] = wp;
+            s1 += (double)wp;
+            s2 += (double)W[(size_t)m * K + k] * (double)ln_b[k];
+        }
+        c1h[m] = (float)s1; c2[m] = (float)s2;
+    }
+    MI_TRY(pack_conv(wf.data(), c2.data(), M, K, false, pc));
+    return pack_vec(c1h.data(), M, pc->Mpad, false, c1);
+}
+
 int Model::pack_vec(const float *v, int n, int npad, bool glu, float **out) {
     std::vector<float> h(npad, 0.f);
     for (int m = 0; m < n; ++m) h[m] = v[glu ? ((m & 1) ? (m >> 1) + n / 2 : (m >> 1)) : m];
@@ -382,21 +400,23 @@ int Model::init(const mi_config &c, const mi_tensor_desc *weights, size_t n) {
             MI_TRY(wt.get(at + ".out_proj.bias", 512, &ob));
             MI_TRY(wt.get(p + ".linear1.weight", 2048 * 512, &w1)); MI_TRY(wt.get(p + ".linear1.bias", 2048, &b1));
             MI_TRY(wt.get(p + ".linear2.weight", 512 * 2048, &w2)); MI_TRY(wt.get(p + ".linear2.bias", 512, &b2));
-            if (cross) {
-                MI_TRY(pack_conv(ipw, ipb, 512, 512, false, &l.q_proj));
-                MI_TRY(pack_conv(ipw + 512 * 512, ipb + 512, 1024, 512, false, &l.kv_proj));
-            } else {
-                MI_TRY(pack_conv(ipw, ipb, 1536, 512, false, &l.qkv_proj));
-            }
-            MI_TRY(pack_conv(ow, ob, 512, 512, false, &l.out_proj));
-            MI_TRY(pack_conv(w1, b1, 2048, 512, false, &l.lin1));
-            MI_TRY(pack_conv(w2, b2, 512, 2048, false, &l.lin2));
+            const float *nw[4] = {}, *nb[4] = {};
             const char *nn[4] = {".norm1", ".norm2", ".norm3", ".norm_out"};
             for (int q = 0; q < 4; ++q) {
-                if (q == 2 && !cross) { l.norm_w[q] = l.norm_b[q] = nullptr; continue; }
-                MI_TRY(wt.get(p + nn[q] + ".weight", 512, &w)); MI_TRY(wt.get(p + nn[q] + ".bias", 512, &b));
-                MI_TRY(pack_vec(w, 512, 512, false, &l.norm_w[q])); MI_TRY(pack_vec(b, 512, 512, false, &l.norm_b[q]));
+                if (q == 2 && !cross) continue;
+                MI_TRY(wt.get(p + nn[q] + ".weight", 512, &nw[q])); MI_TRY(wt.get(p + nn[q] + ".bias", 512, &nb[q]));
             }
+            MI_TRY(pack_vec(nw[3], 512, 512, false, &l.norm_w[3])); MI_TRY(pack_vec(nb[3], 512, 512, false, &l.norm_b[3]));
+            if (cross) {     // q from norm1(own branch), k/v from norm2(other branch), FFN from norm3
+                MI_TRY(pack_linear_ln(ipw, ipb, nw[0], nb[0], 512, 512, &l.q_proj, &l.q_c1));
+                MI_TRY(pack_linear_ln(ipw + 512 * 512, ipb + 512, nw[1], nb[1], 1024, 512, &l.kv_proj, &l.kv_c1));
+                MI_TRY(pack_linear_ln(w1, b1, nw[2], nb[2], 2048, 512, &l.lin1, &l.lin1_c1));
+            } else {
+                MI_TRY(pack_linear_ln(ipw, ipb, nw[0], nb[0], 1536, 512, &l.qkv_proj, &l.qkv_c1));
+                MI_TRY(pack_linear_ln(w1, b1, nw[1], nb[1], 2048, 512, &l.lin1, &l.lin1_c1));
+            }
+            MI_TRY(pack_conv(ow, ob, 512, 512, false, &l.out_proj));
+            MI_TRY(pack_conv(w2, b2, 512, 2048, false, &l.lin2));
             MI_TRY(wt.get(p + ".gamma_1.scale", 512, &w)); MI_TRY(pack_vec(w, 512, 512, false, &l.gamma1));
             MI_TRY(wt.get(p + ".gamma_2.scale", 512, &w)); MI_TRY(pack_vec(w, 512, 512, false, &l.gamma2));
         }
@@ -456,6 +476,8 @@ int Model::alloc_workspace() {
     for (int br = 0; br < 2; ++br) {
         const size_t P = br ? Tt : Tf;
         MI_TRY(A(&w_tr_x[br][0], 512 * P)); MI_TRY(A(&w_tr_x[br][1], 512 * P));
+        for (int q = 0; q < 2; ++q) MI_TRY(dev_alloc((void **)&w_tr_stat[br][q], B * P * sizeof(float2)));
+        MI_TRY(dev_alloc((void **)&w_tr_stat1[br], B * P * sizeof(float2)));
         MI_TRY(A(&w_tr_ln[br], 512 * P)); MI_TRY(A(&w_tr_ln2[br], 512 * Tf)) /* LayerNorm of the OTHER branch in cross layers */;
         MI_TRY(A(&w_tr_qkv[br], 1536 * Tf)) /* cross layers: Q (512 x Tq) + KV (1024 x Tk) */; MI_TRY(A(&w_tr_att[br], 512 * P));
         MI_TRY(A(&w_tr_x1[br], 512 * P)); MI_TRY(A(&w_tr_x2[br], 512 * P)); MI_TRY(A(&w_tr_ffh[br], 2048 * P));
@@ -538,76 +560,61 @@ int Model::run_dconv(const DConvW &w, int C, const Geo &g, float *x, float *tmp,
     return MI_OK;   // two layers: result is back in x
 }
 
-// one transformer layer for branch br: x (B,512,Tq) [+ other (B,512,Tk) for cross] -> out
-int Model::run_tr_layer(int br, int k, int B, const float *x, const float *other, float *out, hipStream_t st) {
+// one transformer layer for branch br: x (B,512,Tq) [+ other (B,512,Tk) for cross] -> out, with the per-token
+// LayerNorm statistics of every tensor that feeds a LayerNorm travelling beside it (xstat / ostat -> outstat):
+// the LayerNorms themselves are folded into the projections that consume them (MI_FLAG_LN).
+int Model::run_tr_layer(int br, int k, int B, const float *x, const float2 *xstat, const float *other, const float2 *ostat,
+                        float *out, float2 *outstat, hipStream_t st) {
     const TrLayerW &l = tr[br][k];
     const bool cross = k & 1;
     const int Tf = 8 * T, Tt = Lt[4];
     const int Tq = br ? Tt : Tf, Tk = cross ? (br ? Tf : Tt) : Tq;
     const Geo gq{B, 1, Tq, 0}, gk{B, 1, Tk, 0};
-    float *ln = w_tr_ln[br], *ln2 = w_tr_ln2[br], *qkv = w_tr_qkv[br], *att = w_tr_att[br], *x1 = w_tr_x1[br], *x2 = w_tr_x2[br],
-          *ffh = w_tr_ffh[br];
+    float *qkv = w_tr_qkv[br], *att = w_tr_att[br], *x1 = w_tr_x1[br], *x2 = w_tr_x2[br], *ffh = w_tr_ffh[br];
     double *stats = br ? w_stats_t : w_stats;
     float2 *st1 = br ? w_st1_t : w_st1;
-    MI_TRY(launch_layernorm_cf(x, B, 512, Tq, l.norm_w[0], l.norm_b[0], nullptr, ln, st));
-    MI_STAGE("tr step 1");
     if (!cross) {
-        mi_conv_desc d = base_desc(l.qkv_proj, tr_ktab512[br], ln, (int64_t)512 * Tq, gq);
-        d.plain = 1;
-        d.epi = MI_EPI_LINEAR; d.y = qkv; d.y_bstride = (int64_t)1536 * Tq; d.y_cstride = Tq;
+        mi_conv_desc d = base_desc(l.qkv_proj, tr_ktab512[br], x, (int64_t)512 * Tq, gq);
+        d.plain = 1; d.epi = MI_EPI_LINEAR; d.flags = MI_FLAG_LN; d.scale = l.qkv_c1; d.pro_stats = (const float *)xstat;
+        d.y = qkv; d.y_bstride = (int64_t)1536 * Tq; d.y_cstride = Tq;
         MI_TRY(conv(d, st));
-    MI_STAGE("tr step 2");
-        MI_TRY(attn(qkv, qkv + (size_t)512 * Tq, qkv + (size_t)1024 * Tq, att, B, Tq, Tq, (int64_t)1536 * Tq,
-                                (int64_t)1536 * Tq, (int64_t)512 * Tq, st));
-    MI_STAGE("tr step 3");
+        MI_TRY(attn(qkv, qkv + (size_t)512 * Tq, qkv + (size_t)1024 * Tq, att, B, Tq, Tq, (int64_t)1536 * Tq, (int64_t)1536 * Tq,
+                    (int64_t)512 * Tq, st));
     } else {
-        MI_TRY(launch_layernorm_cf(other, B, 512, Tk, l.norm_w[1], l.norm_b[1], nullptr, ln2, st));
-    MI_STAGE("tr step 4");
-        mi_conv_desc d = base_desc(l.q_proj, tr_ktab512[br], ln, (int64_t)512 * Tq, gq);
-        d.plain = 1;
-        d.epi = MI_EPI_LINEAR; d.y = qkv; d.y_bstride = (int64_t)512 * Tq; d.y_cstride = Tq;
+        mi_conv_desc d = base_desc(l.q_proj, tr_ktab512[br], x, (int64_t)512 * Tq, gq);
+        d.plain = 1; d.epi = MI_EPI_LINEAR; d.flags = MI_FLAG_LN; d.scale = l.q_c1; d.pro_stats = (const float *)xstat;
+        d.y = qkv; d.y_bstride = (int64_t)512 * Tq; d.y_cstride = Tq;
         MI_TRY(conv(d, st));
-    MI_STAGE("tr step 5");
         float *kv = qkv + (size_t)B * 512 * Tq;
-        mi_conv_desc e = base_desc(l.kv_proj, tr_ktab512[1 - br], ln2, (int64_t)512 * Tk, gk);
-        e.plain = 1;
-        e.epi = MI_EPI_LINEAR; e.y = kv; e.y_bstride = (int64_t)1024 * Tk; e.y_cstride = Tk;
+        mi_conv_desc e = base_desc(l.kv_proj, tr_ktab512[1 - br], other, (int64_t)512 * Tk, gk);
+        e.plain = 1; e.epi = MI_EPI_LINEAR; e.flags = MI_FLAG_LN; e.scale = l.kv_c1; e.pro_stats = (const float *)ostat;
+        e.y = kv; e.y_bstride = (int64_t)1024 * Tk; e.y_cstride = Tk;
         MI_TRY(conv(e, st));
-    MI_STAGE("tr step 6");
-        MI_TRY(attn(qkv, kv, kv + (size_t)512 * Tk, att, B, Tq, Tk, (int64_t)512 * Tq, (int64_t)1024 * Tk,
-                                (int64_t)512 * Tq, st));
-    MI_STAGE("tr step 7");
+        MI_TRY(attn(qkv, kv, kv + (size_t)512 * Tk, att, B, Tq, Tk, (int64_t)512 * Tq, (int64_t)1024 * Tk, (int64_t)512 * Tq, st));
     }
     {   // x1 = x + gamma_1 * (out_proj(att) + b)
         mi_conv_desc d = base_desc(l.out_proj, tr_ktab512[br], att, (int64_t)512 * Tq, gq);
-        d.plain = 1;
-        d.epi = MI_EPI_LINEAR; d.flags = MI_FLAG_SCALE | MI_FLAG_RES; d.scale = l.gamma1; d.res = x;
+        d.plain = 1; d.epi = MI_EPI_LINEAR; d.flags = MI_FLAG_SCALE | MI_FLAG_RES; d.scale = l.gamma1; d.res = x;
         d.y = x1; d.y_bstride = (int64_t)512 * Tq; d.y_cstride = Tq;
         MI_TRY(conv(d, st));
-    MI_STAGE("tr step 8");
     }
-    MI_TRY(launch_layernorm_cf(x1, B, 512, Tq, l.norm_w[cross ? 2 : 1], l.norm_b[cross ? 2 : 1], nullptr, ln, st));
-    MI_STAGE("tr step 9");
+    MI_TRY(launch_token_stats(x1, B, 512, Tq, w_tr_stat1[br], st));
     {
-        mi_conv_desc d = base_desc(l.lin1, tr_ktab512[br], ln, (int64_t)512 * Tq, gq);
-        d.plain = 1;
-        d.epi = MI_EPI_LINEAR; d.flags = MI_FLAG_GELU; d.y = ffh; d.y_bstride = (int64_t)2048 * Tq; d.y_cstride = Tq;
+        mi_conv_desc d = base_desc(l.lin1, tr_ktab512[br], x1, (int64_t)512 * Tq, gq);
+        d.plain = 1; d.epi = MI_EPI_LINEAR; d.flags = MI_FLAG_LN | MI_FLAG_GELU; d.scale = l.lin1_c1;
+        d.pro_stats = (const float *)w_tr_stat1[br];
+        d.y = ffh; d.y_bstride = (int64_t)2048 * Tq; d.y_cstride = Tq;
         MI_TRY(conv(d, st));
-    MI_STAGE("tr step 10");
         mi_conv_desc e = base_desc(l.lin2, tr_ktab2048[br], ffh, (int64_t)2048 * Tq, gq);
-        e.plain = 1;
-        e.epi = MI_EPI_LINEAR; e.flags = MI_FLAG_SCALE | MI_FLAG_RES; e.scale = l.gamma2; e.res = x1;
+        e.plain = 1; e.epi = MI_EPI_LINEAR; e.flags = MI_FLAG_SCALE | MI_FLAG_RES; e.scale = l.gamma2; e.res = x1;
         e.y = x2; e.y_bstride = (int64_t)512 * Tq; e.y_cstride = Tq;
         MI_TRY(conv(e, st));
-    MI_STAGE("tr step 11");
     }
-    // norm_out: GroupNorm(1, 512) over (tokens, channels) per item (transformer.py:258-268)
+    // norm_out: GroupNorm(1, 512) over (tokens, channels) per item (transformer.py:258-268); the apply also
+    // emits the per-token statistics the next layer's LayerNorms need
     MI_TRY(launch_row_stats(x2, B, (int64_t)512 * Tq, (int64_t)512 * Tq, stats, st));
-    MI_STAGE("tr step 12");
     MI_TRY(launch_finalize_stats(stats, B, (double)512 * Tq, 1e-5f, 0, st1, nullptr, st));
-    MI_STAGE("tr step 13");
-    MI_TRY(launch_gn_apply_cf(x2, B, 512, Tq, st1, l.norm_w[3], l.norm_b[3], out, st));
-    MI_STAGE("tr step 14");
+    MI_TRY(launch_gn_apply_tokstats(x2, B, 512, Tq, st1, l.norm_w[3], l.norm_b[3], out, outstat, st));
     return MI_OK;
 }
 
@@ -673,13 +680,15 @@ int Model::forward(const float *mix, float *out, int B, hipStream_t st) {
         mi_conv_desc d = base_desc(chan[br], chan_ktab[br], br ? xt : xf, (int64_t)384 * P, g);
         d.plain = 1; d.epi = MI_EPI_LINEAR; d.y = w_tr_x1[br]; d.y_bstride = (int64_t)512 * P; d.y_cstride = P;
         MI_TRY(conv(d, st));
-        MI_TRY(launch_layernorm_cf(w_tr_x1[br], B, 512, P, norm_in_w[br], norm_in_b[br], pos_emb[br], w_tr_x[br][0], st));
+        MI_TRY(launch_layernorm_cf(w_tr_x1[br], B, 512, P, norm_in_w[br], norm_in_b[br], pos_emb[br], w_tr_x[br][0],
+                                   w_tr_stat[br][0], st));
     }
     MI_STAGE("upsample + norm_in done");
     for (int k = 0; k < 5; ++k) {
         const float *f_in = w_tr_x[0][cur[0]], *t_in = w_tr_x[1][cur[1]];
-        MI_TRY(run_tr_layer(0, k, B, f_in, t_in, w_tr_x[0][cur[0] ^ 1], st));
-        MI_TRY(run_tr_layer(1, k, B, t_in, f_in, w_tr_x[1][cur[1] ^ 1], st));
+        const float2 *f_st = w_tr_stat[0][cur[0]], *t_st = w_tr_stat[1][cur[1]];
+        MI_TRY(run_tr_layer(0, k, B, f_in, f_st, t_in, t_st, w_tr_x[0][cur[0] ^ 1], w_tr_stat[0][cur[0] ^ 1], st));
+        MI_TRY(run_tr_layer(1, k, B, t_in, t_st, f_in, f_st, w_tr_x[1][cur[1] ^ 1], w_tr_stat[1][cur[1] ^ 1], st));
         cur[0] ^= 1; cur[1] ^= 1;
         MI_STAGE("transformer layer done");
     }

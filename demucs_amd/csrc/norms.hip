@@ -79,37 +79,71 @@ __global__ __launch_bounds__(256) void row_affine_kernel(const float *__restrict
         y[base + i] = (x[base + i] - nm.x) * nm.y;
 }
 
-// LayerNorm over C channels of channel-first tokens x[b][C][T]; optional additive table pe[C][T].
-// grid (ceil(T/64), B), block 256: lane = token, wave w owns channels [w*C/4, (w+1)*C/4).
-__global__ __launch_bounds__(256) void layernorm_cf_kernel(const float *__restrict__ x, int C, int T, const float *__restrict__ w,
-                                                           const float *__restrict__ bvec, const float *__restrict__ pe, float eps,
-                                                           float *__restrict__ y) {
+// Token-tile kernel on channel-first tokens x[b][C][T]: grid (ceil(T/64), B), block 256; lane = token, wave w
+// owns channels [w*C/4, (w+1)*C/4).  One template, three uses:
+//   MODE 0  LayerNorm (+ optional additive table pe[C][T]) -> y, and (mean, rstd) of y over channels -> ostat
+//   MODE 1  per-token (mean, rstd) of x only -> ostat                      (LayerNorm folded into the next GEMM)
+//   MODE 2  GroupNorm(1) apply y = (x - gm[b]) * gr[b] * w[c] + b[c] -> y, and (mean, rstd) of y -> ostat
+// Variances use sums shifted by the token's first value (no cancellation), float32.
+template <int MODE>
+__global__ __launch_bounds__(256) void token_tile_kernel(const float *__restrict__ x, int C, int T, const float *__restrict__ w,
+                                                         const float *__restrict__ bvec, const float *__restrict__ pe,
+                                                         const float2 *__restrict__ gstat, float eps, float *__restrict__ y,
+                                                         float2 *__restrict__ ostat) {
     __shared__ float red[4][64][2];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int t = blockIdx.x * 64 + lane;
     const bool ok = t < T;
     const size_t base = (size_t)blockIdx.y * C * T + (ok ? t : 0);
     const int cw = C / 4, c0 = wv * cw;
-    const float x0 = x[base];                         // shift: removes cancellation in sum of squares
+    const float inv_c = 1.0f / (float)C;
+    float mean = 0.f, rstd = 1.f;
+    if (MODE == 0 || MODE == 1) {                     // statistics of the input over channels
+        const float x0 = x[base];
+        float s1 = 0.f, s2 = 0.f;
+        for (int c = c0; c < c0 + cw; ++c) {
+            const float v = x[base + (size_t)c * T] - x0;
+            s1 += v; s2 += v * v;
+        }
+        red[wv][lane][0] = s1; red[wv][lane][1] = s2;
+        __syncthreads();
+        s1 = red[0][lane][0] + red[1][lane][0] + red[2][lane][0] + red[3][lane][0];
+        s2 = red[0][lane][1] + red[1][lane][1] + red[2][lane][1] + red[3][lane][1];
+        const float dm = s1 * inv_c;
+        mean = x0 + dm;
+        rstd = 1.0f / sqrtf(fmaxf(s2 * inv_c - dm * dm, 0.f) + eps);
+        if (MODE == 1) {
+            if (ok && wv == 0) ostat[(size_t)blockIdx.y * T + t] = make_float2(mean, rstd);
+            return;
+        }
+        __syncthreads();                              // red[] is reused below
+    } else {
+        const float2 g = gstat[blockIdx.y];
+        mean = g.x; rstd = g.y;
+    }
+    // produce y and the statistics of y (shifted by y at channel 0 of this token)
+    float y0;
+    {
+        float v = (x[base] - mean) * rstd * w[0] + bvec[0];
+        if (MODE == 0 && pe) v += pe[ok ? t : 0];
+        y0 = v;
+    }
     float s1 = 0.f, s2 = 0.f;
     for (int c = c0; c < c0 + cw; ++c) {
-        const float v = x[base + (size_t)c * T] - x0;
-        s1 += v; s2 += v * v;
+        float v = (x[base + (size_t)c * T] - mean) * rstd * w[c] + bvec[c];
+        if (MODE == 0 && pe) v += pe[(size_t)c * T + (ok ? t : 0)];
+        if (ok) y[base + (size_t)c * T] = v;
+        const float dv = v - y0;
+        s1 += dv; s2 += dv * dv;
     }
+    if (!ostat) return;
     red[wv][lane][0] = s1; red[wv][lane][1] = s2;
     __syncthreads();
-    s1 = red[0][lane][0] + red[1][lane][0] + red[2][lane][0] + red[3][lane][0];
-    s2 = red[0][lane][1] + red[1][lane][1] + red[2][lane][1] + red[3][lane][1];
-    const float inv_c = 1.0f / (float)C;
-    const float dm = s1 * inv_c;
-    const float mean = x0 + dm;
-    const float var = fmaxf(s2 * inv_c - dm * dm, 0.f);
-    const float rstd = 1.0f / sqrtf(var + eps);
-    if (!ok) return;
-    for (int c = c0; c < c0 + cw; ++c) {
-        float v = (x[base + (size_t)c * T] - mean) * rstd * w[c] + bvec[c];
-        if (pe) v += pe[(size_t)c * T + t];
-        y[base + (size_t)c * T] = v;
+    if (ok && wv == 0) {
+        s1 = red[0][lane][0] + red[1][lane][0] + red[2][lane][0] + red[3][lane][0];
+        s2 = red[0][lane][1] + red[1][lane][1] + red[2][lane][1] + red[3][lane][1];
+        const float dm = s1 * inv_c;
+        ostat[(size_t)blockIdx.y * T + t] = make_float2(y0 + dm, 1.0f / sqrtf(fmaxf(s2 * inv_c - dm * dm, 0.f) + eps));
     }
 }
 
@@ -168,9 +202,25 @@ int launch_row_affine(const float *x, int rows, int64_t count, const float2 *nor
 }
 
 int launch_layernorm_cf(const float *x, int B, int C, int T, const float *w, const float *b, const float *pe, float *y,
-                        hipStream_t st) {
+                        float2 *ostat, hipStream_t st) {
     MI_REQUIRE(C % 4 == 0, "layernorm: C %% 4 != 0");
-    hipLaunchKernelGGL(layernorm_cf_kernel, dim3(ceil_div(T, 64), B), dim3(256), 0, st, x, C, T, w, b, pe, 1e-5f, y);
+    hipLaunchKernelGGL(token_tile_kernel<0>, dim3(ceil_div(T, 64), B), dim3(256), 0, st, x, C, T, w, b, pe, nullptr, 1e-5f, y, ostat);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+
+int launch_token_stats(const float *x, int B, int C, int T, float2 *ostat, hipStream_t st) {
+    MI_REQUIRE(C % 4 == 0, "token_stats: C %% 4 != 0");
+    hipLaunchKernelGGL(token_tile_kernel<1>, dim3(ceil_div(T, 64), B), dim3(256), 0, st, x, C, T, nullptr, nullptr, nullptr, nullptr,
+                       1e-5f, nullptr, ostat);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+
+int launch_gn_apply_tokstats(const float *x, int B, int C, int T, const float2 *gstat, const float *w, const float *b, float *y,
+                             float2 *ostat, hipStream_t st) {
+    MI_REQUIRE(C % 4 == 0, "gn_apply: C %% 4 != 0");
+    hipLaunchKernelGGL(token_tile_kernel<2>, dim3(ceil_div(T, 64), B), dim3(256), 0, st, x, C, T, w, b, nullptr, gstat, 1e-5f, y, ostat);
     MI_CHECK_LAUNCH();
     return MI_OK;
 }
