@@ -35,6 +35,24 @@ int launch_gn_apply_cf(const float *x, int B, int C, int T, const float2 *stats,
 int launch_gn_gelu(float *x, int B, int C, int Cs, int D1, int D2, int row_mode, const float2 *stats, const float *w, const float *b,
                    hipStream_t st);
 
+// dconv_row.hip: both DConv layers of one frequency-branch row fused in LDS
+struct DConvRowLayer {
+    const float *w0;    // [C][3][HA]   conv3 weights, hidden index fastest (HA = C/8 rounded up to 4)
+    const float *b0;    // [HA]
+    const float *g1w, *g1b;   // [HA]  GroupNorm(1, C/8) affine
+    const float *w3;    // [2C][HA]    1x1 weights, natural row order (value rows then gate rows)
+    const float *b3, *g2w, *g2b;   // [2C]
+    const float *ls;    // [C]         LayerScale
+};
+struct DConvRowArgs {
+    DConvRowLayer l[2];
+    const float *x;     // [B][C][Fr][T]
+    float *y;           // same shape (may alias x)
+    int Fr, T;
+};
+bool dconv_row_supported(int C, int T);
+int launch_dconv_row(const DConvRowArgs &a, int C, int rows, hipStream_t st);
+
 // gemm_conv.hip
 int launch_conv(const mi_conv_desc &d, hipStream_t st);
 int conv_pick_tile(int M);

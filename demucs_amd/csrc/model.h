@@ -23,7 +23,11 @@ struct DConvLayerW {
     mi_ktab_entry *ktab3 = nullptr, *ktab1 = nullptr;
     float *gn1_w = nullptr, *gn1_b = nullptr, *gn2_w = nullptr, *gn2_b = nullptr, *ls = nullptr;
 };
-struct DConvW { DConvLayerW l[2]; };
+struct DConvW {
+    DConvLayerW l[2];
+    bool has_row = false;          // frequency-branch C = 48 / 96: fused LDS-resident row kernel
+    DConvRowLayer row[2];
+};
 
 struct EncW {
     PackedConv conv, rewrite;
@@ -108,7 +112,7 @@ struct Model {
     int pack_linear_ln(const float *W, const float *bias, const float *ln_w, const float *ln_b, int M, int K, PackedConv *pc,
                        float **c1);
     int make_ktab(const Gather &g, int Kpad, mi_ktab_entry **out);
-    int load_dconv(const WeightTable &wt, const std::string &prefix, int C, int64_t chan_stride, int D2, DConvW *dw);
+    int load_dconv(const WeightTable &wt, const std::string &prefix, int C, int64_t chan_stride, int D2, bool freq, DConvW *dw);
     int alloc_workspace();
     int run_dconv(const DConvW &w, int C, const Geo &g, float *x, float *tmp, float *hidden, double *stats, float2 *st1, float2 *st2,
                   hipStream_t st);

@@ -227,8 +227,9 @@ int Model::make_ktab(const Gather &g, int Kpad, mi_ktab_entry **out) {
     return upload(build_ktab(g, Kpad), out);
 }
 
-int Model::load_dconv(const WeightTable &wt, const std::string &prefix, int C, int64_t chan_stride, int D2, DConvW *dw) {
+int Model::load_dconv(const WeightTable &wt, const std::string &prefix, int C, int64_t chan_stride, int D2, bool freq, DConvW *dw) {
     const int h = C / 8;
+    dw->has_row = freq && dconv_row_supported(C, D2);
     for (int d = 0; d < 2; ++d) {
         DConvLayerW &l = dw->l[d];
         const std::string p = prefix + ".dconv.layers." + std::to_string(d);
@@ -258,6 +259,23 @@ int Model::load_dconv(const WeightTable &wt, const std::string &prefix, int C, i
         MI_TRY(pack_vec(g2w, 2 * C, l.conv1.Mpad, true, &l.gn2_w));
         MI_TRY(pack_vec(g2b, 2 * C, l.conv1.Mpad, true, &l.gn2_b));
         MI_TRY(pack_vec(ls, C, C, false, &l.ls));
+        if (dw->has_row) {          // packing of dconv_row.hip: hidden index fastest, padded to a multiple of 4
+            const int HA = (h + 3) / 4 * 4;
+            std::vector<float> w0r((size_t)C * 3 * HA, 0.f), b0r(HA, 0.f), g1wr(HA, 0.f), g1br(HA, 0.f), w3r((size_t)2 * C * HA, 0.f);
+            for (int m = 0; m < h; ++m) {
+                b0r[m] = b0[m]; g1wr[m] = g1w[m]; g1br[m] = g1b[m];
+                for (int c = 0; c < C; ++c)
+                    for (int tap = 0; tap < 3; ++tap) w0r[((size_t)c * 3 + tap) * HA + m] = w0[((size_t)m * C + c) * 3 + tap];
+            }
+            for (int m = 0; m < 2 * C; ++m)
+                for (int k = 0; k < h; ++k) w3r[(size_t)m * HA + k] = w3[(size_t)m * h + k];
+            float *p0, *p1, *p2, *p3, *p4, *p5, *p6, *p7;
+            MI_TRY(upload(w0r, &p0)); MI_TRY(upload(b0r, &p1)); MI_TRY(upload(g1wr, &p2)); MI_TRY(upload(g1br, &p3));
+            MI_TRY(upload(w3r, &p4));
+            MI_TRY(pack_vec(b3, 2 * C, 2 * C, false, &p5)); MI_TRY(pack_vec(g2w, 2 * C, 2 * C, false, &p6));
+            MI_TRY(pack_vec(g2b, 2 * C, 2 * C, false, &p7));
+            dw->row[d] = DConvRowLayer{p0, p1, p2, p3, p4, p5, p6, p7, l.ls};
+        }
     }
     return MI_OK;
 }
@@ -311,7 +329,7 @@ int Model::init(const mi_config &c, const mi_tensor_desc *weights, size_t n) {
         MI_TRY(make_ktab(Gather{Cin, 8, 1, 1, 1, 2, 0, (int64_t)kFr[i] * T, T}, e.conv.Kpad, &e.ktab_conv));
         MI_TRY(pack_conv(rw, rb, 2 * C, C, true, &e.rewrite));
         MI_TRY(make_ktab(Gather{C, 1, 1, 1, 1, 0, 0, (int64_t)kFr[i + 1] * T, T}, e.rewrite.Kpad, &e.ktab_rw));
-        MI_TRY(load_dconv(wt, p, C, (int64_t)kFr[i + 1] * T, T, &e.dconv));
+        MI_TRY(load_dconv(wt, p, C, (int64_t)kFr[i + 1] * T, T, true, &e.dconv));
 
         const int Cint = i ? kCh[i - 1] : 2;
         const std::string pt = "tencoder." + std::to_string(i);
@@ -324,7 +342,7 @@ int Model::init(const mi_config &c, const mi_tensor_desc *weights, size_t n) {
         MI_TRY(make_ktab(Gather{Cint, 1, 8, 1, 1, 0, 2, (int64_t)Lt[i], Lt[i]}, te.conv.Kpad, &te.ktab_conv));
         MI_TRY(pack_conv(rw, rb, 2 * C, C, true, &te.rewrite));
         MI_TRY(make_ktab(Gather{C, 1, 1, 1, 1, 0, 0, (int64_t)Lt[i + 1], Lt[i + 1]}, te.rewrite.Kpad, &te.ktab_rw));
-        MI_TRY(load_dconv(wt, pt, C, (int64_t)Lt[i + 1], Lt[i + 1], &te.dconv));
+        MI_TRY(load_dconv(wt, pt, C, (int64_t)Lt[i + 1], Lt[i + 1], false, &te.dconv));
     }
     {   // freq embedding table: 0.2 * (10 * weight).t()  -> [48][512]   (htdemucs.py:577-582, hdemucs.py:60-66)
         const float *ew;
@@ -347,7 +365,7 @@ int Model::init(const mi_config &c, const mi_tensor_desc *weights, size_t n) {
         DecW &dd = dec[j];
         MI_TRY(pack_conv(rw, rb, 2 * C, C * 9, true, &dd.rewrite));
         MI_TRY(make_ktab(Gather{C, 3, 3, 1, 1, 1, 1, (int64_t)Fr * T, T}, dd.rewrite.Kpad, &dd.ktab_rw));
-        MI_TRY(load_dconv(wt, p, C, (int64_t)Fr * T, T, &dd.dconv));
+        MI_TRY(load_dconv(wt, p, C, (int64_t)Fr * T, T, true, &dd.dconv));
         MI_TRY(pack_convtr(w, b, C, Cout, &dd.convtr));
         MI_TRY(make_ktab(Gather{C, 2, 1, -1, 1, 0, 0, (int64_t)Fr * T, T}, dd.convtr.Kpad, &dd.ktab_tr));
 
@@ -360,7 +378,7 @@ int Model::init(const mi_config &c, const mi_tensor_desc *weights, size_t n) {
         DecW &td = tdec[j];
         MI_TRY(pack_conv(rw, rb, 2 * C, C * 3, true, &td.rewrite));
         MI_TRY(make_ktab(Gather{C, 1, 3, 1, 1, 0, 1, (int64_t)L, L}, td.rewrite.Kpad, &td.ktab_rw));
-        MI_TRY(load_dconv(wt, pt, C, (int64_t)L, L, &td.dconv));
+        MI_TRY(load_dconv(wt, pt, C, (int64_t)L, L, false, &td.dconv));
         MI_TRY(pack_convtr(w, b, C, Coutt, &td.convtr));
         MI_TRY(make_ktab(Gather{C, 1, 2, 1, -1, 0, 0, (int64_t)L, L}, td.convtr.Kpad, &td.ktab_tr));
     }
@@ -536,6 +554,20 @@ int Model::run_dconv(const DConvW &w, int C, const Geo &g, float *x, float *tmp,
     const int h = C / 8, hp = round_up(h, 16);
     const int64_t P = (int64_t)g.D1 * g.D2;
     const int rows = g.row_mode ? g.B * g.D1 : g.B;
+    if (w.has_row && g.row_mode == 1) {      // both layers in one LDS-resident pass, in place
+        DConvRowArgs a{{w.row[0], w.row[1]}, x, x, g.D1, g.D2};
+        if (prof.on) {
+            Profiler::Pending p{101, prof.get(), prof.get(), 2.0 * 2.0 * (3.0 * C * h + 2.0 * 2 * C * h) * (double)rows * g.D2,
+                                2.0 * 4.0 * C * (double)rows * g.D2};
+            MI_HIP(hipEventRecord(p.a, st));
+            const int r = launch_dconv_row(a, C, rows, st);
+            MI_HIP(hipEventRecord(p.b, st));
+            prof.pending.push_back(p);
+            snprintf(prof.rows[101].name, sizeof(prof.rows[101].name), "dconv_row_kernel");
+            return r;
+        }
+        return launch_dconv_row(a, C, rows, st);
+    }
     const double cnt_row = g.row_mode ? (double)g.D2 : (double)P;
     float *src = x, *dst = tmp;
     for (int dlayer = 0; dlayer < 2; ++dlayer) {
