@@ -67,8 +67,22 @@ __global__ __launch_bounds__(256, (TM * TN == 4 ? 3 : 4)) void conv_gemm_kernel(
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
-    // m-tile index fastest: the workgroups that share one activation tile are dispatched together
-    const int mt = blockIdx.x % MT, nt = blockIdx.x / MT;
+    // XCD-aware tile order.  Workgroups are dealt round-robin over the 8 XCDs (private L2 each), so the MT
+    // workgroups that share one activation tile (same nt) are given ids that are equal mod 8: they run on ONE
+    // XCD and the tile is fetched into one L2 instead of eight.  Groups of 8 consecutive ids = 8 different nt.
+    int mt, nt;
+    {
+        const int NT = gridDim.x / MT, full = (NT / 8) * 8;
+        const int id = blockIdx.x, per8 = 8 * MT;
+        if (id < full * MT) {
+            const int g = id / per8, r = id - g * per8;
+            nt = g * 8 + (r & 7);
+            mt = r >> 3;
+        } else {                                   // tail: fewer than 8 column tiles left
+            const int r = id - full * MT;
+            mt = r % MT; nt = full + r / MT;
+        }
+    }
     const int m0 = mt * BM, n0 = nt * BN;
     const int P = d.O1 * d.O2;
 
