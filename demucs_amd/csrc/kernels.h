@@ -21,7 +21,7 @@ int launch_istft(const float *y, int B, int S, int L, const float2 *denorm, cons
 
 // norms.hip
 int launch_row_stats(const float *x, int rows, int64_t count, int64_t row_stride, double *stats, hipStream_t st);
-int launch_finalize_stats(const double *stats, int rows, double count, float eps, int mode, float2 *out_a, float2 *out_b,
+int launch_finalize_stats(double *stats, int rows, double count, float eps, int mode, float2 *out_a, float2 *out_b,
                           hipStream_t st);
 int launch_row_affine(const float *x, int rows, int64_t count, const float2 *norm, float *y, hipStream_t st);
 int launch_layernorm_cf(const float *x, int B, int C, int T, const float *w, const float *b, const float *pe, float *y,

@@ -507,6 +507,8 @@ int Model::alloc_workspace() {
     const size_t max_rows = B * 512;
     MI_TRY(dev_alloc((void **)&w_stats, max_rows * kStatSlots * 2 * sizeof(double)));
     MI_TRY(dev_alloc((void **)&w_stats_t, max_rows * kStatSlots * 2 * sizeof(double)));
+    MI_HIP(hipMemset(w_stats, 0, max_rows * kStatSlots * 2 * sizeof(double)));      // finalize_stats re-zeroes after each use
+    MI_HIP(hipMemset(w_stats_t, 0, max_rows * kStatSlots * 2 * sizeof(double)));
     MI_TRY(dev_alloc((void **)&w_st1, max_rows * sizeof(float2)));
     MI_TRY(dev_alloc((void **)&w_st2, max_rows * sizeof(float2)));
     MI_TRY(dev_alloc((void **)&w_st1_t, max_rows * sizeof(float2)));
@@ -572,12 +574,10 @@ int Model::run_dconv(const DConvW &w, int C, const Geo &g, float *x, float *tmp,
     float *src = x, *dst = tmp;
     for (int dlayer = 0; dlayer < 2; ++dlayer) {
         const DConvLayerW &l = w.l[dlayer];
-        MI_HIP(hipMemsetAsync(stats, 0, sizeof(double) * 2 * kStatSlots * rows, st));
         mi_conv_desc d = base_desc(l.conv3, l.ktab3, src, (int64_t)C * P, g);
         d.epi = MI_EPI_BIAS_STATS; d.y = hidden; d.y_bstride = (int64_t)hp * P; d.y_cstride = P; d.stats = stats;
         MI_TRY(conv(d, st));
         MI_TRY(launch_finalize_stats(stats, rows, cnt_row * h, 1e-5f, 0, st1, nullptr, st));
-        MI_HIP(hipMemsetAsync(stats, 0, sizeof(double) * 2 * kStatSlots * rows, st));
         MI_TRY(launch_gn_gelu(hidden, g.B, h, hp, g.D1, g.D2, g.row_mode, st1, l.gn1_w, l.gn1_b, st));
         mi_conv_desc e = base_desc(l.conv1, l.ktab1, hidden, (int64_t)hp * P, g);
         e.plain = 1;
@@ -662,7 +662,6 @@ int Model::forward(const float *mix, float *out, int B, hipStream_t st) {
     MI_TRY(launch_finalize_stats(w_stats_t, B, 2.0 * SL, 1e-5f, 1, w_norm_t, w_denorm_t, st));
     MI_TRY(launch_row_affine(mix, B, (int64_t)2 * SL, w_norm_t, w_xt0, st));
     MI_STAGE("time normalisation done");
-    MI_HIP(hipMemsetAsync(w_stats, 0, sizeof(double) * 2 * kStatSlots * B, st));
     MI_TRY(launch_stft_frames(mix, B, SL, fft, w_zt, w_stats, st));
     MI_TRY(launch_finalize_stats(w_stats, B, 4.0 * 2048 * T, 1e-5f, 1, w_norm_f, w_denorm_f, st));
     MI_TRY(launch_cac_transpose(w_zt, B, T, w_norm_f, w_x0, st));

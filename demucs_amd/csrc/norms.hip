@@ -48,14 +48,17 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const float *__restrict_
 
 // mode 0: GroupNorm   -> out_a[row] = (mean, 1/sqrt(var_biased + eps))
 // mode 1: item norm   -> out_a[row] = (mean, 1/(eps + std_unbiased)), out_b[row] = (mean, std_unbiased)
-__global__ void finalize_stats_kernel(const double *__restrict__ stats, int rows, double count, float eps, int mode,
+// The slots are zeroed again after being read: the workspace statistics buffers are zero at creation and
+// every producer pass is followed by exactly one finalize, so no memset launch is needed between uses.
+__global__ void finalize_stats_kernel(double *__restrict__ stats, int rows, double count, float eps, int mode,
                                       float2 *__restrict__ out_a, float2 *__restrict__ out_b) {
     const int row = blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= rows) return;
     double s1 = 0.0, s2 = 0.0;
     for (int s = 0; s < kStatSlots; ++s) {
-        s1 += stats[((size_t)row * kStatSlots + s) * 2];
-        s2 += stats[((size_t)row * kStatSlots + s) * 2 + 1];
+        double *p = stats + ((size_t)row * kStatSlots + s) * 2;
+        s1 += p[0]; s2 += p[1];
+        p[0] = 0.0; p[1] = 0.0;
     }
     const double mean = s1 / count;
     double m2 = s2 - s1 * mean;          // sum (x - mean)^2
@@ -180,14 +183,13 @@ int launch_gn_gelu(float *x, int B, int C, int Cs, int D1, int D2, int row_mode,
 }
 
 int launch_row_stats(const float *x, int rows, int64_t count, int64_t row_stride, double *stats, hipStream_t st) {
-    MI_HIP(hipMemsetAsync(stats, 0, sizeof(double) * 2 * kStatSlots * rows, st));
     const int nblk = (int)std::min<int64_t>(256, (count + 4095) / 4096);
     hipLaunchKernelGGL(row_stats_kernel, dim3(nblk, rows), dim3(256), 0, st, x, count, row_stride, stats);
     MI_CHECK_LAUNCH();
     return MI_OK;
 }
 
-int launch_finalize_stats(const double *stats, int rows, double count, float eps, int mode, float2 *out_a, float2 *out_b,
+int launch_finalize_stats(double *stats, int rows, double count, float eps, int mode, float2 *out_a, float2 *out_b,
                           hipStream_t st) {
     hipLaunchKernelGGL(finalize_stats_kernel, dim3(ceil_div(rows, 64)), dim3(64), 0, st, stats, rows, count, eps, mode, out_a, out_b);
     MI_CHECK_LAUNCH();
