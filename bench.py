@@ -54,7 +54,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=8, help="segments per batched forward")
+    ap.add_argument("--batch", type=int, default=32, help="segments per batched forward (workspace ~0.57 GB each)")
     ap.add_argument("--seconds", type=int, default=TRACK_SECONDS_PER_GPU, help="track seconds per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pcie", action="store_true", help="also time host->device->host apply_model (reported separately)")

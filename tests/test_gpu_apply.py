@@ -116,3 +116,32 @@ def test_shorter_segment_override_and_errors():
     assert torch.equal(fast, want)
     with pytest.raises(ValueError):
         P.apply_model(m, mix, shifts=0, segment=9)              # longer than the training length (htdemucs.py:521-524)
+
+
+def test_full_size_track_properties():
+    """BASELINE configs[1] at full size (3-minute track, 31 segments, one 31-segment batched forward):
+    finite, bit-identical to the per-segment route, and two randomly chosen segments of the stitched result
+    agree with the float64 oracle run on those segments alone (interior samples that only they cover)."""
+    from oracle import htdemucs_oracle as O
+    cfg = HTDemucsConfig()
+    sd = synthetic_state_dict(cfg, 0)
+    m = HTDemucs(cfg.sources, max_batch=31)
+    m.load_state_dict(sd)
+    length = 180 * 44100
+    mix = torch.from_numpy(synth_mix(1, length, "noise"))[None].cuda()
+    out = P.apply_model(m, mix, shifts=0, overlap=0.25)
+    assert out.shape == (1, 4, 2, length) and bool(torch.isfinite(out).all())
+    m2 = HTDemucs(cfg.sources, max_batch=4)
+    m2.load_state_dict(sd)
+    slow = P.apply_model(PerSegment(m2), mix, shifts=0, overlap=0.25)
+    assert torch.equal(out, slow)
+    osd = O.to_torch_state(sd, torch.float64)
+    stride = int(0.75 * SL)
+    for k in (7, 22):
+        off = k * stride
+        seg = mix[..., off:off + SL].cpu().double()
+        with torch.no_grad():
+            want = O.htdemucs_forward(osd, seg, 4)
+        lo, hi = SL - stride, stride                   # samples covered by segment k only (weight ratio = 1)
+        err = (out[..., off + lo:off + hi].cpu().double() - want[..., lo:hi]).abs().max().item()
+        assert err <= TOL, (k, err)
