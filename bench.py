@@ -122,6 +122,12 @@ def main():
         dom_ms = dom["ms"] / dom["launches"]
         achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
         total_ms = sum(r["ms"] for r in rows)
+        traffic, traffic_src = None, None        # HBM bytes per launch from the committed PMC passes of this same command
+        tpath = os.path.join(ROOT, "profiles", "round1_traffic.json")
+        if os.path.exists(tpath) and world == 1 and args.batch == 32 and args.seconds == TRACK_SECONDS_PER_GPU:
+            entry = json.load(open(tpath)).get(dom["name"])
+            if entry:
+                traffic, traffic_src = entry["traffic_bytes_per_launch"], "profiles/round1_traffic.json: " + entry["method"]
         result = {
             "metric": "real-time factor (audio-sec/wall-sec) htdemucs 4-stem 44.1kHz stereo",
             "value": round(length / SR / sec_per_step, 2), "unit": "audio-sec/wall-sec",
@@ -133,7 +139,9 @@ def main():
                                    "(synthetic_state_dict seed 0), stems left in HBM",
                        "parallelism": f"segments sharded over {world} GPU(s)" + (", one RCCL all-gather of slabs" if world > 1 else "")},
             "roofline": {"bound": "mfma", "kernel": dom["name"], "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": round(dom["bytes"] / dom["launches"]),
+                         "algorithmic_flops_per_launch": round(dom["flops"] / dom["launches"]),
                          "launches": dom["launches"], "avg_launch_ms": round(dom_ms, 4),
                          "share_of_instrumented_time": round(dom["ms"] / total_ms, 3)},
             "kernels": [{"name": r["name"], "launches": r["launches"], "ms": round(r["ms"], 3),

@@ -1,0 +1,65 @@
+"""Turn two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; one counter per pass as the TCC slots
+require) of `python3 bench.py --steps K --warmup 1 --no-cpu-baseline` into per-launch HBM traffic of
+the engine's kernel classes, written to profiles/<name>.json (bench.py copies the matching entry
+into roofline.traffic).
+
+    python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/round1_traffic.json
+
+gfx950 corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE and WRITE_SIZE are in KiB;
+FETCH_SIZE reports exactly half of the bytes of wide (16 B/lane) coalesced reads, which is how the
+GEMM / attention kernels load, so reads are doubled; WRITE_SIZE is taken as is.
+"""
+import collections
+import csv
+import glob
+import json
+import re
+import sys
+
+EPI = {0: "linear", 1: "glu", 2: "bias_stats", 3: "stats_only", 4: "gn_glu", 5: "convtr"}
+TILE = {(2, 2, 2, 2): 128, (1, 4, 3, 1): 96, (1, 4, 2, 1): 64, (1, 4, 1, 1): 32}
+
+
+def klass(name):
+    m = re.search(r"conv_gemm_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (true|false)>", name)
+    if m:
+        wm, wn, tm, tn, epi, _, plain = m.groups()
+        return f"conv_gemm<{EPI[int(epi)]},tile{TILE[(int(wm), int(wn), int(tm), int(tn))]}{',1x1' if plain == 'true' else ''}>"
+    for k in ("attention_kernel", "dconv_row_kernel"):
+        if k in name:
+            return k
+    return None
+
+
+def collect(d, counter):
+    out = collections.defaultdict(lambda: [0, 0.0])
+    for f in glob.glob(d + "/*counter_collection.csv"):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != counter:
+                continue
+            k = klass(r["Kernel_Name"])
+            if k:
+                out[k][0] += 1
+                out[k][1] += float(r["Counter_Value"])
+    return out
+
+
+def main():
+    fetch, write, dst = sys.argv[1:4]
+    f, w = collect(fetch, "FETCH_SIZE"), collect(write, "WRITE_SIZE")
+    res = {}
+    for k in sorted(f):
+        n, fs = f[k]
+        wn, ws = w.get(k, [0, 0.0])
+        rd = 2.0 * fs * 1024 / n
+        wr = ws * 1024 / max(1, wn)
+        res[k] = {"launches_sampled": n, "read_bytes_per_launch": round(rd), "write_bytes_per_launch": round(wr),
+                  "traffic_bytes_per_launch": round(rd + wr),
+                  "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, KiB units, FETCH_SIZE x2 (gfx950 wide-read correction)"}
+    json.dump(res, open(dst, "w"), indent=1)
+    for k, v in res.items():
+        print(f"{k:40s} {v['traffic_bytes_per_launch'] / 1e6:9.1f} MB/launch  (read {v['read_bytes_per_launch'] / 1e6:.1f}, write {v['write_bytes_per_launch'] / 1e6:.1f})")
+
+
+if __name__ == "__main__":
+    main()
