@@ -47,6 +47,7 @@ APPLY_CASES = {
     "apply_sl_plus_1": dict(wseeds=[1], mix=lambda: synth_mix(3, SL + 1, "noise")),
     "apply_shifts2": dict(wseeds=[0], mix=lambda: synth_mix(4, 300000, "tones")),
     "apply_bag2_shift1": dict(wseeds=[10, 11], mix=lambda: synth_mix(5, 400000, "noise")),
+    "apply_bag4_onehot_shifts2": dict(wseeds=[10, 11, 12, 13], mix=lambda: synth_mix(9, 280000, "tones")),
     "apply_nosplit_short": dict(wseeds=[0], mix=lambda: synth_mix(6, 200000, "tones")),
     "apply_overlap10_tp2": dict(wseeds=[1], mix=lambda: synth_mix(8, int(1.5 * SL), "noise")),
 }

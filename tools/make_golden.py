@@ -142,6 +142,10 @@ def main():
                   shifts=2, split=True, overlap=0.25)
     apply_fixture("apply_bag2_shift1", cfg4, [10, 11], [[1., 0., 0.5, 0.25], [0., 1., 0.5, 0.75]],
                   synth_mix(5, 400000, "noise"), rseed=3, shifts=1, split=True, overlap=0.25)
+    # BASELINE config 3 in miniature: bag of 4 with the one-hot per-source weights of remote/htdemucs_ft.yaml, shifts=2
+    apply_fixture("apply_bag4_onehot_shifts2", cfg4, [10, 11, 12, 13],
+                  [[1., 0., 0., 0.], [0., 1., 0., 0.], [0., 0., 1., 0.], [0., 0., 0., 1.]],
+                  synth_mix(9, 280000, "tones"), rseed=0, shifts=2, split=True, overlap=0.25)
     apply_fixture("apply_nosplit_short", cfg4, [0], None, synth_mix(6, 200000, "tones"), shifts=0, split=False)
     apply_fixture("apply_overlap10_tp2", cfg4, [1], None, synth_mix(8, int(1.5 * SL), "noise"),
                   shifts=0, split=True, overlap=0.1, transition_power=2.0)
