@@ -24,13 +24,12 @@ int launch_row_stats(const float *x, int rows, int64_t count, int64_t row_stride
 int launch_finalize_stats(double *stats, int rows, double count, float eps, int mode, float2 *out_a, float2 *out_b,
                           hipStream_t st);
 int launch_row_affine(const float *x, int rows, int64_t count, const float2 *norm, float *y, hipStream_t st);
+int launch_row_denorm(const float *x, int rows, int64_t count, const float2 *denorm, float *y, hipStream_t st);
 int launch_layernorm_cf(const float *x, int B, int C, int T, const float *w, const float *b, const float *pe, float *y,
                         float2 *ostat, hipStream_t st);
 int launch_token_stats(const float *x, int B, int C, int T, float2 *ostat, hipStream_t st);
 int launch_gn_apply_tokstats(const float *x, int B, int C, int T, const float2 *gstat, const float *w, const float *b, float *y,
                              float2 *ostat, hipStream_t st);
-int launch_gn_apply_cf(const float *x, int B, int C, int T, const float2 *stats, const float *w, const float *b, float *y,
-                       hipStream_t st);
 
 int launch_gn_gelu(float *x, int B, int C, int Cs, int D1, int D2, int row_mode, const float2 *stats, const float *w, const float *b,
                    hipStream_t st);

@@ -92,7 +92,7 @@ struct Model {
     float *w_a = nullptr, *w_b = nullptr, *w_c = nullptr, *w_h = nullptr;
     float *w_ta = nullptr, *w_tb = nullptr, *w_tc = nullptr, *w_th = nullptr;
     float2 *w_tr_stat[2][2] = {}, *w_tr_stat1[2] = {};   // per-token (mean, rstd) of the layer inputs / of x1
-    float *w_tr_x[2][2] = {}, *w_tr_ln[2] = {}, *w_tr_ln2[2] = {}, *w_tr_qkv[2] = {}, *w_tr_att[2] = {}, *w_tr_x1[2] = {},
+    float *w_tr_x[2][2] = {}, *w_tr_qkv[2] = {}, *w_tr_att[2] = {}, *w_tr_x1[2] = {},
           *w_tr_x2[2] = {}, *w_tr_ffh[2] = {};
     float *w_yspec = nullptr, *w_ytime = nullptr, *w_yt = nullptr, *w_fr = nullptr;
     double *w_stats = nullptr, *w_stats_t = nullptr;
@@ -102,6 +102,8 @@ struct Model {
     ~Model();
     int init(const mi_config &c, const mi_tensor_desc *weights, size_t n);
     int forward(const float *mix, float *out, int B, hipStream_t st);
+    int forward_core(const float *mix, float *spec_out, float *time_out, int B, hipStream_t st);
+    int run_core(const float *mix, int B, hipStream_t st);
 
    private:
     int dev_alloc(void **p, size_t bytes);

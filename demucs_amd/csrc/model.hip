@@ -496,7 +496,6 @@ int Model::alloc_workspace() {
         MI_TRY(A(&w_tr_x[br][0], 512 * P)); MI_TRY(A(&w_tr_x[br][1], 512 * P));
         for (int q = 0; q < 2; ++q) MI_TRY(dev_alloc((void **)&w_tr_stat[br][q], B * P * sizeof(float2)));
         MI_TRY(dev_alloc((void **)&w_tr_stat1[br], B * P * sizeof(float2)));
-        MI_TRY(A(&w_tr_ln[br], 512 * P)); MI_TRY(A(&w_tr_ln2[br], 512 * Tf)) /* LayerNorm of the OTHER branch in cross layers */;
         MI_TRY(A(&w_tr_qkv[br], 1536 * Tf)) /* cross layers: Q (512 x Tq) + KV (1024 x Tk) */; MI_TRY(A(&w_tr_att[br], 512 * P));
         MI_TRY(A(&w_tr_x1[br], 512 * P)); MI_TRY(A(&w_tr_x2[br], 512 * P)); MI_TRY(A(&w_tr_ffh[br], 2048 * P));
     }
@@ -654,8 +653,27 @@ int Model::run_tr_layer(int br, int k, int B, const float *x, const float2 *xsta
 // forward
 // ------------------------------------------------------------------------------------------------
 int Model::forward(const float *mix, float *out, int B, hipStream_t st) {
-    MI_REQUIRE(B >= 1 && B <= cfg.max_batch, "forward: batch %d outside [1, %d]", B, cfg.max_batch);
     MI_REQUIRE(mix && out, "forward: null buffer");
+    MI_TRY(run_core(mix, B, st));
+    // ---- de-normalise, iSTFT, add the time branch (htdemucs.py:624-657) -----------------------------
+    MI_TRY(launch_istft(w_yspec, B, S, SL, w_denorm_f, w_ytime, w_denorm_t, fft, w_yt, w_fr, out, st));
+    MI_STAGE("istft done");
+    return MI_OK;
+}
+
+// HTDemucs.forward_core (htdemucs.py:662-759): the network without iSTFT / branch sum.
+// spec_out (B, S, 4, 2048, T) = decoder output * std + mean; time_out (B, S, 2, L) = time decoder * stdt + meant.
+int Model::forward_core(const float *mix, float *spec_out, float *time_out, int B, hipStream_t st) {
+    MI_REQUIRE(mix && spec_out && time_out, "forward_core: null buffer");
+    MI_TRY(run_core(mix, B, st));
+    MI_TRY(launch_row_denorm(w_yspec, B, (int64_t)4 * S * 2048 * T, w_denorm_f, spec_out, st));
+    MI_TRY(launch_row_denorm(w_ytime, B, (int64_t)2 * S * SL, w_denorm_t, time_out, st));
+    return MI_OK;
+}
+
+// everything up to the decoder outputs: leaves w_yspec / w_ytime and the (mean, std) pairs in the workspace
+int Model::run_core(const float *mix, int B, hipStream_t st) {
+    MI_REQUIRE(B >= 1 && B <= cfg.max_batch, "forward: batch %d outside [1, %d]", B, cfg.max_batch);
     const int Tf = 8 * T, Tt = Lt[4];
     // ---- input statistics and normalisation (htdemucs.py:545-554) --------------------------------
     MI_TRY(launch_row_stats(mix, B, (int64_t)2 * SL, (int64_t)2 * SL, w_stats_t, st));
@@ -770,9 +788,6 @@ int Model::forward(const float *mix, float *out, int B, hipStream_t st) {
         }
     }
     MI_STAGE("decoders done");
-    // ---- de-normalise, iSTFT, add the time branch (htdemucs.py:624-657) -----------------------------
-    MI_TRY(launch_istft(w_yspec, B, S, SL, w_denorm_f, w_ytime, w_denorm_t, fft, w_yt, w_fr, out, st));
-    MI_STAGE("istft done");
     return MI_OK;
 }
 

@@ -150,18 +150,6 @@ __global__ __launch_bounds__(256) void token_tile_kernel(const float *__restrict
     }
 }
 
-// y[b][c][t] = (x - mean[b]) * rstd[b] * w[c] + bias[c]   (GroupNorm(1, C) apply), grid (ceil(T/256), C, B)
-__global__ __launch_bounds__(256) void gn_apply_cf_kernel(const float *__restrict__ x, int C, int T, const float2 *__restrict__ st,
-                                                          const float *__restrict__ w, const float *__restrict__ bvec,
-                                                          float *__restrict__ y) {
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= T) return;
-    const int c = blockIdx.y, b = blockIdx.z;
-    const float2 s = st[b];
-    const size_t i = ((size_t)b * C + c) * T + t;
-    y[i] = (x[i] - s.x) * s.y * w[c] + bvec[c];
-}
-
 // x[b][c][d1][d2] <- gelu((x - mean[row]) * rstd[row] * w[c] + bias[c]) in place; row = b*D1 + d1 (row_mode 1) or b.
 // GroupNorm(1) + GELU of the DConv hidden tensor (demucs.py:139); Cs = channels allocated per item.  grid (ceil(D1*D2/256), C, B)
 __global__ __launch_bounds__(256) void gn_gelu_kernel(float *__restrict__ x, int C, int Cs, int D1, int D2, int row_mode,
@@ -196,6 +184,22 @@ int launch_finalize_stats(double *stats, int rows, double count, float eps, int 
     return MI_OK;
 }
 
+// y[row][i] = x[row][i] * std[row] + mean[row]   (htdemucs.py:626,656), denorm = (mean, std)
+__global__ __launch_bounds__(256) void row_denorm_kernel(const float *__restrict__ x, int64_t count, const float2 *__restrict__ denorm,
+                                                         float *__restrict__ y) {
+    const float2 d = denorm[blockIdx.y];
+    const size_t base = (size_t)blockIdx.y * count;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256)
+        y[base + i] = x[base + i] * d.y + d.x;
+}
+
+int launch_row_denorm(const float *x, int rows, int64_t count, const float2 *denorm, float *y, hipStream_t st) {
+    const int nblk = (int)std::min<int64_t>(2048, (count + 255) / 256);
+    hipLaunchKernelGGL(row_denorm_kernel, dim3(nblk, rows), dim3(256), 0, st, x, count, denorm, y);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+
 int launch_row_affine(const float *x, int rows, int64_t count, const float2 *norm, float *y, hipStream_t st) {
     const int nblk = (int)std::min<int64_t>(1024, (count + 255) / 256);
     hipLaunchKernelGGL(row_affine_kernel, dim3(nblk, rows), dim3(256), 0, st, x, count, norm, y);
@@ -223,13 +227,6 @@ int launch_gn_apply_tokstats(const float *x, int B, int C, int T, const float2 *
                              float2 *ostat, hipStream_t st) {
     MI_REQUIRE(C % 4 == 0, "gn_apply: C %% 4 != 0");
     hipLaunchKernelGGL(token_tile_kernel<2>, dim3(ceil_div(T, 64), B), dim3(256), 0, st, x, C, T, w, b, nullptr, gstat, 1e-5f, y, ostat);
-    MI_CHECK_LAUNCH();
-    return MI_OK;
-}
-
-int launch_gn_apply_cf(const float *x, int B, int C, int T, const float2 *stats, const float *w, const float *b, float *y,
-                       hipStream_t st) {
-    hipLaunchKernelGGL(gn_apply_cf_kernel, dim3(ceil_div(T, 256), C, B), dim3(256), 0, st, x, C, T, stats, w, b, y);
     MI_CHECK_LAUNCH();
     return MI_OK;
 }

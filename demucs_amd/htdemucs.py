@@ -200,6 +200,29 @@ class HTDemucs:
                                                 nb, C.c_void_p(_lib.current_stream_ptr())), "mi_model_forward")
         return out
 
+    def forward_core(self, mag: Optional[torch.Tensor], mix: torch.Tensor):
+        """HTDemucs.forward_core (htdemucs.py:662-759): (spec_out (B,S,4,2048,T), time_out (B,S,2,L)).
+        `mag` must be `_magnitude(_spec(mix))` by the reference's contract; the engine recomputes it from
+        `mix`, so it may be None (a given `mag` is only shape-checked)."""
+        SL = self.segment_length
+        if mix.dim() != 3 or mix.shape[1] != self.audio_channels or mix.shape[2] != SL or mix.dtype != torch.float32:
+            raise ValueError(f"expected float32 (B, {self.audio_channels}, {SL}), got {tuple(mix.shape)} {mix.dtype}")
+        B, S, T = mix.shape[0], len(self.sources), -(-SL // 1024)
+        if mag is not None and tuple(mag.shape) != (B, 4, 2048, T):
+            raise ValueError(f"mag must be (B, 4, 2048, {T}), got {tuple(mag.shape)}")
+        handle = self._ensure_handle()
+        mix = mix.contiguous()
+        spec = torch.empty(B, S, 4, 2048, T, device=mix.device, dtype=torch.float32)
+        tout = torch.empty(B, S, self.audio_channels, SL, device=mix.device, dtype=torch.float32)
+        lib = _lib.load()
+        with torch.cuda.device(self._device):
+            for b0 in range(0, B, self.max_batch):
+                nb = min(self.max_batch, B - b0)
+                _lib.check(lib.mi_model_forward_core(C.c_void_p(handle), mix[b0:b0 + nb].data_ptr(), spec[b0:b0 + nb].data_ptr(),
+                                                     tout[b0:b0 + nb].data_ptr(), nb, C.c_void_p(_lib.current_stream_ptr())),
+                           "mi_model_forward_core")
+        return spec, tout
+
     def __call__(self, mix: torch.Tensor) -> torch.Tensor:
         """HTDemucs.forward in eval mode (htdemucs.py:527-660): shorter inputs are right-padded with
         zeros to the training length and the output cropped back."""

@@ -60,6 +60,13 @@ void mi_model_destroy(void *handle);
  *      (B, n_sources, 2, segment_length).  1 <= B <= max_batch. ---------------------------- */
 int mi_model_forward(void *handle, const float *mix_dev, float *out_dev, int32_t B, void *stream);
 
+/* ---- `HTDemucs.forward_core(mag, mix)` (demucs/htdemucs.py:662-759; the fork's ONNX "core", docs/onnx.md):
+ *      the network without the iSTFT and the branch sum.  `mag` is by contract `_magnitude(_spec(mix))`, which the
+ *      engine derives from mix_dev (B, 2, segment_length) itself.  spec_out_dev: (B, S, 4, 2048, T);
+ *      time_out_dev: (B, S, 2, segment_length). -------------------------------------------------------- */
+int mi_model_forward_core(void *handle, const float *mix_dev, float *spec_out_dev, float *time_out_dev, int32_t B,
+                          void *stream);
+
 /* Debug / parity aid: copy an internal activation left behind by the last mi_model_forward
  * (first B items) into dst_dev (may be NULL to query *numel_per_item only).  Names: "x0" (normalised CaC spectrogram),
  * "xt0", "enc0".."enc3", "tenc0".."tenc3" (encoder outputs = skip tensors), "tr_f", "tr_t"

@@ -321,6 +321,8 @@ def htdemucs_forward(sd: Dict[str, Tensor], mix: Tensor, n_sources: int = 4, seg
             taps[f"dec{j}"] = x; taps[f"tdec{j}"] = xt
     Fq, T = x.shape[-2:]
     x = x.view(B, S, -1, Fq, T) * std[:, None] + mean[:, None]     # :625-626
+    if taps is not None: taps["spec_out"] = x                      # forward_core outputs (htdemucs.py:752-759)
+    if taps is not None: taps["time_out"] = xt.view(B, S, -1, segment_length) * stdt[:, None] + meant[:, None]
     x = istft_from_cac(x, segment_length)
     if taps is not None: taps["istft"] = x
     xt = xt.view(B, S, -1, segment_length) * stdt[:, None] + meant[:, None]

@@ -82,6 +82,30 @@ def test_forward_full_resolution_vs_float64_oracle():
     assert torch.equal(single[0], out[1]), "batched and single-item forwards must be bit-identical"
 
 
+def test_forward_core_contract():
+    """forward_core (htdemucs.py:662-759): spec_out / time_out before iSTFT, against the float64 oracle;
+    iSTFT(spec_out) + time_out must reproduce the full forward."""
+    import ctypes as C
+    from demucs_amd import _lib
+    cfg = HTDemucsConfig()
+    sd = synthetic_state_dict(cfg, 5)
+    model = make_model(cfg, 5, max_batch=1)
+    mix = torch.from_numpy(synth_mix(61, SL, "tones"))[None]
+    spec, tout = model.forward_core(None, mix.cuda())
+    taps = {}
+    with torch.no_grad():
+        O.htdemucs_forward(O.to_torch_state(sd, torch.float64), mix.double(), 4, taps=taps)
+    es = (spec.cpu().double() - taps["spec_out"]).abs().max().item()
+    et = (tout.cpu().double() - taps["time_out"]).abs().max().item()
+    assert es <= 2e-4 * taps["spec_out"].abs().max().item() and et <= 2e-4 * taps["time_out"].abs().max().item(), (es, et)
+    wav = torch.empty(1, 4, 2, SL, device="cuda")
+    _lib.check(_lib.load().mi_istft_cac(spec.data_ptr(), 1, 4, SL, wav.data_ptr(), C.c_void_p(_lib.current_stream_ptr())), "istft")
+    full = model(mix.cuda())
+    assert (wav + tout - full).abs().max().item() < 2e-5
+    with pytest.raises(ValueError):
+        model.forward_core(torch.zeros(1, 4, 2048, 10), mix.cuda())
+
+
 def test_model_rejects_cpu_and_bad_shapes():
     cfg = HTDemucsConfig()
     m = HTDemucs(cfg.sources)
