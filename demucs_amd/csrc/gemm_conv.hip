@@ -223,21 +223,32 @@ __global__ __launch_bounds__(256, (TM * TN == 4 ? 3 : 4)) void conv_gemm_kernel(
             if (EPI == MI_EPI_LINEAR && (LFLAGS & (MI_FLAG_SCALE | MI_FLAG_LN))) load_rows16(d.scale, mbase, auxr);
             if (EPI == MI_EPI_GN_GLU) { load_rows16(d.gn_w, mbase, auxr); load_rows16(d.gn_b, mbase, aux2r); }
             if (EPI == MI_EPI_LINEAR) {
+                // 32-bit row offsets from one 64-bit column base; for residual epilogues all 16 residual loads of
+                // the tile are issued first, so they are in flight together instead of one load -> store round
+                // trip per value
+                const size_t colbase = c.valid ? (size_t)c.b * d.y_bstride + c.p : 0;
+                float *const ycol = d.y + colbase;
+                const int cs = (int)d.y_cstride;
+                float resv[16];
+                if (LFLAGS & MI_FLAG_RES) {
+                    const float *const rcol = d.res + colbase;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = mbase + (r & 3) + 8 * (r >> 2);
+                        resv[r] = rcol[(c.valid && m < d.M) ? m * cs : 0];
+                    }
+                }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    if ((r & 3) == 0) __builtin_amdgcn_sched_barrier(0);   // 4 values in flight, not 64 (GELU temporaries)
                     const int m = mbase + (r & 3) + 8 * (r >> 2);
                     float v;
                     if (LFLAGS & MI_FLAG_LN) v = lnstat.y * (acc[a][b][r] - lnstat.x * auxr[r]) + biasr[r];
                     else v = acc[a][b][r] + biasr[r];
                     if (LFLAGS & MI_FLAG_GELU) v = gelu_exact(v);
                     if (LFLAGS & MI_FLAG_SCALE) v *= auxr[r];
-                    // branch-free: out-of-range rows / columns are stored to a per-lane sink word, so the
-                    // epilogue stays one basic block and accumulators leave the AGPR file a few at a time
-                    const bool ok = c.valid && m < d.M;
-                    const size_t idx = ok ? (size_t)c.b * d.y_bstride + (size_t)m * d.y_cstride + c.p : 0;
-                    if (LFLAGS & MI_FLAG_RES) v += d.res[idx];
-                    *(ok ? d.y + idx : sink) = v;
+                    if (LFLAGS & MI_FLAG_RES) v += resv[r];
+                    // branch-free: out-of-range rows / columns are stored to a per-lane sink word
+                    *((c.valid && m < d.M) ? ycol + m * cs : sink) = v;
                 }
             } else if (EPI == MI_EPI_GLU || EPI == MI_EPI_GN_GLU) {
 #pragma unroll
@@ -259,7 +270,6 @@ __global__ __launch_bounds__(256, (TM * TN == 4 ? 3 : 4)) void conv_gemm_kernel(
             } else if (EPI == MI_EPI_BIAS_STATS || EPI == MI_EPI_STATS_ONLY) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    if ((r & 3) == 0) __builtin_amdgcn_sched_barrier(0);
                     const int m = mbase + (r & 3) + 8 * (r >> 2);
                     const float v = acc[a][b][r] + biasr[r];
                     const bool ok = c.valid && m < d.M;
@@ -354,6 +364,7 @@ int launch_conv(const mi_conv_desc &din, hipStream_t st) {
     mi_conv_desc d = din;
     if (!d.sink) d.sink = conv_sink();
     MI_REQUIRE(d.sink, "conv: could not allocate the store sink");
+    MI_REQUIRE((int64_t)d.Mpad * d.y_cstride < (1ll << 31), "conv: output channel stride too large for 32-bit row offsets");
     MI_REQUIRE(d.Kpad % BK == 0 && d.Kpad >= BK, "conv: Kpad %d must be a positive multiple of %d", d.Kpad, BK);
     MI_REQUIRE(d.Mpad % 4 == 0, "conv: Mpad %d must be a multiple of 4", d.Mpad);
     MI_REQUIRE(d.O2 >= 32 || d.row_mode == 0 || (d.epi != MI_EPI_BIAS_STATS && d.epi != MI_EPI_STATS_ONLY),
