@@ -95,7 +95,7 @@ int mi_model_tap(void *handle, const char *name, float *dst_dev, int32_t B, int6
     else if (n.size() == 4 && n.compare(0, 3, "enc") == 0 && n[3] >= '0' && n[3] <= '3') {
         const int i = n[3] - '0'; *ptr_dev = m->w_skip[i]; *numel_per_item = (int64_t)ch[i] * fr[i] * T;
     } else if (n.size() == 5 && n.compare(0, 4, "tenc") == 0 && n[4] >= '0' && n[4] <= '3') {
-        const int i = n[4] - '0'; *ptr_dev = m->w_skip_t[i]; *numel_per_item = (int64_t)ch[i] * m->Lt[i + 1];
+        const int i = n[4] - '0'; *ptr_dev = m->w_skip_t[i]; *numel_per_item = (int64_t)ch[i] * m->Lp[i + 1];   // rows padded to a multiple of 4
     }
     if (!*ptr_dev) return set_error(MI_EINVAL, "mi_model_tap: unknown tap '%s'", name);
     if (dst_dev) {

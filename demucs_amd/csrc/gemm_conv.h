@@ -70,6 +70,10 @@ typedef struct mi_conv_desc {
     int32_t plain;          /* 1: the gather is the identity over input channels (1x1 conv / linear with channel
                                stride O1*O2): enables the table-free float4 loader when shapes allow             */
     int32_t reserved;
+    int32_t o2_valid;       /* 0, or the number of REAL positions along o2 when O2 is a padded row pitch (columns with
+                               o2 >= o2_valid are computed but never stored nor counted): lets rows whose length is
+                               not a multiple of 4 keep 16-byte aligned starts and use the float4 loader            */
+    int32_t reserved2;
     float *sink;            /* >= 256 floats that out-of-range epilogue stores are diverted to; NULL = library-owned */
 } mi_conv_desc;
 

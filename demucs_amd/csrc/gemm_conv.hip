@@ -22,7 +22,7 @@ struct ColInfo {   // decomposition of one output column n = (b, o1, o2)
     bool valid;
 };
 
-__device__ __forceinline__ ColInfo decompose(int n, int N, int P, int O2) {
+__device__ __forceinline__ ColInfo decompose(int n, int N, int P, int O2, int o2v) {
     ColInfo c;
     c.valid = n < N;
     const int nn = c.valid ? n : 0;
@@ -30,6 +30,7 @@ __device__ __forceinline__ ColInfo decompose(int n, int N, int P, int O2) {
     c.p = nn - c.b * P;
     c.o1 = c.p / O2;
     c.o2 = c.p - c.o1 * O2;
+    c.valid = c.valid && c.o2 < o2v;       // o2v < O2: O2 is a padded row pitch
     return c;
 }
 
@@ -101,7 +102,8 @@ __global__ __launch_bounds__(256, (TM * TN == 4 ? 3 : 4)) void conv_gemm_kernel(
     // ---- B loader ----------------------------------------------------------------------------------
     // generic: this thread owns column (tid & 127), rows khalf + 2*j;  plain: 4 columns x rows r, r + 8
     const int khalf = wave >> 1;
-    const ColInfo lc = decompose(n0 + (PLAIN ? (tid & 31) * 4 : (tid & 127)), N, P, d.O2);
+    const int o2v = d.o2_valid ? d.o2_valid : d.O2;
+    const ColInfo lc = decompose(n0 + (PLAIN ? (tid & 31) * 4 : (tid & 127)), N, P, d.O2, PLAIN ? d.O2 : o2v);
     const int i1b = lc.o1 * d.S1, i2b = lc.o2 * d.S2;
     const float *xcol = d.x + (size_t)lc.b * d.x_bstride + (PLAIN ? (size_t)lc.p : (size_t)i1b * d.D2 + i2b);
     const int prow = tid >> 5;                                   // plain: first row of this thread
@@ -201,7 +203,7 @@ __global__ __launch_bounds__(256, (TM * TN == 4 ? 3 : 4)) void conv_gemm_kernel(
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
         const int n = n0 + (wn * TN + b) * 32 + li;
-        const ColInfo c = decompose(n, N, P, d.O2);
+        const ColInfo c = decompose(n, N, P, d.O2, o2v);
         const int row = d.row_mode ? c.b * d.O1 + c.o1 : c.b;
         float s1 = 0.f, s2 = 0.f;
         float2 lnstat = make_float2(0.f, 1.f);

@@ -292,6 +292,7 @@ int Model::init(const mi_config &c, const mi_tensor_desc *weights, size_t n) {
     MI_REQUIRE(T % 4 == 0, "segment_length %d gives %d STFT frames; the engine needs a multiple of 4", SL, T);
     Lt[0] = SL;
     for (int i = 0; i < 4; ++i) Lt[i + 1] = (Lt[i] + 3) / 4;
+    for (int i = 0; i < 5; ++i) Lp[i] = round_up(Lt[i], 4);
     MI_REQUIRE(Lt[4] % 4 == 0, "time branch bottleneck length %d must be a multiple of 4", Lt[4]);
     WeightTable wt;
     for (size_t i = 0; i < n; ++i) wt.t[weights[i].name] = {weights[i].data, weights[i].numel};
@@ -339,10 +340,10 @@ int Model::init(const mi_config &c, const mi_tensor_desc *weights, size_t n) {
         MI_TRY(wt.get(pt + ".rewrite.bias", 2 * C, &rb));
         EncW &te = tenc[i];
         MI_TRY(pack_conv(w, b, C, Cint * 8, false, &te.conv));
-        MI_TRY(make_ktab(Gather{Cint, 1, 8, 1, 1, 0, 2, (int64_t)Lt[i], Lt[i]}, te.conv.Kpad, &te.ktab_conv));
+        MI_TRY(make_ktab(Gather{Cint, 1, 8, 1, 1, 0, 2, (int64_t)Lp[i], Lp[i]}, te.conv.Kpad, &te.ktab_conv));
         MI_TRY(pack_conv(rw, rb, 2 * C, C, true, &te.rewrite));
-        MI_TRY(make_ktab(Gather{C, 1, 1, 1, 1, 0, 0, (int64_t)Lt[i + 1], Lt[i + 1]}, te.rewrite.Kpad, &te.ktab_rw));
-        MI_TRY(load_dconv(wt, pt, C, (int64_t)Lt[i + 1], Lt[i + 1], false, &te.dconv));
+        MI_TRY(make_ktab(Gather{C, 1, 1, 1, 1, 0, 0, (int64_t)Lp[i + 1], Lp[i + 1]}, te.rewrite.Kpad, &te.ktab_rw));
+        MI_TRY(load_dconv(wt, pt, C, (int64_t)Lp[i + 1], Lp[i + 1], false, &te.dconv));
     }
     {   // freq embedding table: 0.2 * (10 * weight).t()  -> [48][512]   (htdemucs.py:577-582, hdemucs.py:60-66)
         const float *ew;
@@ -369,7 +370,7 @@ int Model::init(const mi_config &c, const mi_tensor_desc *weights, size_t n) {
         MI_TRY(pack_convtr(w, b, C, Cout, &dd.convtr));
         MI_TRY(make_ktab(Gather{C, 2, 1, -1, 1, 0, 0, (int64_t)Fr * T, T}, dd.convtr.Kpad, &dd.ktab_tr));
 
-        const int L = Lt[4 - j];
+        const int L = Lp[4 - j];          // row pitch of this level's time-branch tensors
         const std::string pt = "tdecoder." + std::to_string(j);
         MI_TRY(wt.get(pt + ".conv_tr.weight", (int64_t)C * Coutt * 8, &w));
         MI_TRY(wt.get(pt + ".conv_tr.bias", Coutt, &b));
@@ -480,7 +481,7 @@ int Model::alloc_workspace() {
     MI_TRY(A(&w_x0, (size_t)4 * 2048 * T));
     size_t big = 0;
     for (int i = 0; i < 4; ++i) {
-        const size_t nf = (size_t)kCh[i] * kFr[i + 1] * T, nt = (size_t)kCh[i] * Lt[i + 1];
+        const size_t nf = (size_t)kCh[i] * kFr[i + 1] * T, nt = (size_t)kCh[i] * Lp[i + 1];
         MI_TRY(A(&w_skip[i], nf)); MI_TRY(A(&w_skip_t[i], nt));
         big = std::max(big, std::max(nf, nt));
     }
@@ -538,13 +539,16 @@ static bool debug_sync() {
 struct Geo {          // geometry of one activation tensor family
     int B, D1, D2;    // batch, rows (freq bins or 1), columns (frames / samples)
     int row_mode;     // 1: DConv / GroupNorm rows are (b, d1) (frequency branch), 0: b
+    int ld;           // row pitch in floats (>= D2, multiple of 4 when it differs): time-branch rows are padded
+    int pitch() const { return ld ? ld : D2; }
 };
 
 static mi_conv_desc base_desc(const PackedConv &pc, const mi_ktab_entry *ktab, const float *x, int64_t x_bs, const Geo &g) {
     mi_conv_desc d;
     memset(&d, 0, sizeof(d));
     d.wt = pc.wt; d.M = pc.M; d.Mpad = pc.Mpad; d.K = pc.K; d.Kpad = pc.Kpad; d.ktab = ktab; d.bias = pc.bias; d.tile_m = pc.tile;
-    d.x = x; d.x_bstride = x_bs; d.B = g.B; d.D1 = g.D1; d.D2 = g.D2; d.O1 = g.D1; d.O2 = g.D2; d.S1 = 1; d.S2 = 1;
+    d.x = x; d.x_bstride = x_bs; d.B = g.B; d.D1 = g.D1; d.D2 = g.D2; d.O1 = g.D1; d.O2 = g.pitch(); d.S1 = 1; d.S2 = 1;
+    d.o2_valid = g.pitch() != g.D2 ? g.D2 : 0;       // enumerate the padded row, mask the padding columns
     d.row_mode = g.row_mode;
     return d;
 }
@@ -553,7 +557,7 @@ static mi_conv_desc base_desc(const PackedConv &pc, const mi_ktab_entry *ktab, c
 int Model::run_dconv(const DConvW &w, int C, const Geo &g, float *x, float *tmp, float *hidden, double *stats, float2 *st1,
                      float2 *st2, hipStream_t st) {
     const int h = C / 8, hp = round_up(h, 16);
-    const int64_t P = (int64_t)g.D1 * g.D2;
+    const int64_t P = (int64_t)g.D1 * g.pitch();
     const int rows = g.row_mode ? g.B * g.D1 : g.B;
     if (w.has_row && g.row_mode == 1) {      // both layers in one LDS-resident pass, in place
         DConvRowArgs a{{w.row[0], w.row[1]}, x, x, g.D1, g.D2};
@@ -569,7 +573,7 @@ int Model::run_dconv(const DConvW &w, int C, const Geo &g, float *x, float *tmp,
         }
         return launch_dconv_row(a, C, rows, st);
     }
-    const double cnt_row = g.row_mode ? (double)g.D2 : (double)P;
+    const double cnt_row = g.row_mode ? (double)g.D2 : (double)g.D1 * g.D2;
     float *src = x, *dst = tmp;
     for (int dlayer = 0; dlayer < 2; ++dlayer) {
         const DConvLayerW &l = w.l[dlayer];
@@ -577,7 +581,7 @@ int Model::run_dconv(const DConvW &w, int C, const Geo &g, float *x, float *tmp,
         d.epi = MI_EPI_BIAS_STATS; d.y = hidden; d.y_bstride = (int64_t)hp * P; d.y_cstride = P; d.stats = stats;
         MI_TRY(conv(d, st));
         MI_TRY(launch_finalize_stats(stats, rows, cnt_row * h, 1e-5f, 0, st1, nullptr, st));
-        MI_TRY(launch_gn_gelu(hidden, g.B, h, hp, g.D1, g.D2, g.row_mode, st1, l.gn1_w, l.gn1_b, st));
+        MI_TRY(launch_gn_gelu(hidden, g.B, h, hp, g.D1, g.pitch(), g.row_mode, st1, l.gn1_w, l.gn1_b, st));
         mi_conv_desc e = base_desc(l.conv1, l.ktab1, hidden, (int64_t)hp * P, g);
         e.plain = 1;
         e.epi = MI_EPI_STATS_ONLY; e.stats = stats;
@@ -707,10 +711,10 @@ int Model::run_core(const float *mix, int B, hipStream_t st) {
             MI_STAGE("enc rewrite done");
         }
         {   // time branch
-            const Geo gin{B, 1, Lt[i], 0}, go{B, 1, Lt[i + 1], 0};
-            const int64_t P = Lt[i + 1];
-            mi_conv_desc d = base_desc(tenc[i].conv, tenc[i].ktab_conv, xt, (int64_t)Cint * Lt[i], gin);
-            d.O2 = Lt[i + 1]; d.S2 = 4; d.epi = MI_EPI_LINEAR; d.flags = MI_FLAG_GELU;
+            const Geo gin{B, 1, Lt[i], 0, Lp[i]}, go{B, 1, Lt[i + 1], 0, Lp[i + 1]};
+            const int64_t P = Lp[i + 1];
+            mi_conv_desc d = base_desc(tenc[i].conv, tenc[i].ktab_conv, xt, (int64_t)Cint * Lp[i], gin);
+            d.O2 = Lp[i + 1]; d.o2_valid = Lt[i + 1]; d.S2 = 4; d.epi = MI_EPI_LINEAR; d.flags = MI_FLAG_GELU;
             d.y = w_ta; d.y_bstride = C * P; d.y_cstride = P;
             MI_TRY(conv(d, st));
             MI_TRY(run_dconv(tenc[i].dconv, C, go, w_ta, w_tb, w_th, w_stats_t, w_st1_t, w_st2_t, st));
@@ -772,16 +776,16 @@ int Model::run_core(const float *mix, int B, hipStream_t st) {
             MI_STAGE("dec freq layer done");
         }
         {   // time branch
-            const int L = Lt[4 - j], Lout = Lt[3 - j];
-            const Geo g{B, 1, L, 0};
+            const int Lv = Lt[4 - j], L = Lp[4 - j], Lout = Lt[3 - j], Lpo = Lp[3 - j];   // valid lengths and row pitches
+            const Geo g{B, 1, Lv, 0, L};
             mi_conv_desc r = base_desc(tdec[j].rewrite, tdec[j].ktab_rw, dtin, (int64_t)C * L, g);
             r.epi = MI_EPI_GLU; r.y = w_ta; r.y_bstride = (int64_t)C * L; r.y_cstride = L;
             MI_TRY(conv(r, st));
             MI_TRY(run_dconv(tdec[j].dconv, C, g, w_ta, w_tb, w_th, w_stats_t, w_st1_t, w_st2_t, st));
             const int Cout = last ? 2 * S : kCh[2 - j];
             mi_conv_desc t = base_desc(tdec[j].convtr, tdec[j].ktab_tr, w_ta, (int64_t)C * L, g);
-            t.O2 = L + 1; t.epi = MI_EPI_CONVTR; t.out_len = Lout;
-            t.y_cstride = Lout; t.y_bstride = (int64_t)Cout * Lout;
+            t.O2 = Lv + 1; t.o2_valid = 0; t.epi = MI_EPI_CONVTR; t.out_len = Lout;     // q = 0 .. Lv, scattered to 4q + r - 2
+            t.y_cstride = Lpo; t.y_bstride = (int64_t)Cout * Lpo;
             if (last) t.y = w_ytime;
             else { t.flags |= MI_FLAG_GELU | MI_FLAG_RES; t.res = w_skip_t[2 - j]; t.y = dtin; }
             MI_TRY(conv(t, st));

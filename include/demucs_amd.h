@@ -69,7 +69,8 @@ int mi_model_forward_core(void *handle, const float *mix_dev, float *spec_out_de
 
 /* Debug / parity aid: copy an internal activation left behind by the last mi_model_forward
  * (first B items) into dst_dev (may be NULL to query *numel_per_item only).  Names: "x0" (normalised CaC spectrogram),
- * "xt0", "enc0".."enc3", "tenc0".."tenc3" (encoder outputs = skip tensors), "tr_f", "tr_t"
+ * "xt0", "enc0".."enc3", "tenc0".."tenc3" (encoder outputs = skip tensors; time-branch rows are stored with a
+ * pitch rounded up to 4 samples), "tr_f", "tr_t"
  * (transformer outputs, channel-first), "yspec", "ytime" (decoder outputs before iSTFT). */
 int mi_model_tap(void *handle, const char *name, float *dst_dev, int32_t B, int64_t *numel_per_item, void *stream);
 
