@@ -54,6 +54,136 @@ __device__ __forceinline__ float gather_b(const mi_conv_desc &d, const mi_ktab_e
 }
 
 // PLAIN = 1x1 / linear layer with K % 16 == 0 and (O1*O2) % 4 == 0: no gather table, float4 activation loads.
+// Epilogue shared by the register-staged and the LDS-DMA main loops.
+// acc[a][b][r] is C[m][n] with n = n0 + (wn*TN + b)*32 + li, m = m0 + (wm*TM + a)*32 + (r & 3) + 8 * (r >> 2) + 4 * lh
+template <int TM, int TN, int EPI, int LFLAGS>
+__device__ __forceinline__ void conv_epilogue(const mi_conv_desc &d, f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int N,
+                                              int P, int o2v) {
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+    const int slot = blockIdx.x % kStatSlots;
+    float *const sink = d.sink + tid;
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+        const int n = n0 + (wn * TN + b) * 32 + li;
+        const ColInfo c = decompose(n, N, P, d.O2, o2v);
+        const int row = d.row_mode ? c.b * d.O1 + c.o1 : c.b;
+        float s1 = 0.f, s2 = 0.f;
+        float2 lnstat = make_float2(0.f, 1.f);
+        if (EPI == MI_EPI_LINEAR && (LFLAGS & MI_FLAG_LN))
+            lnstat = reinterpret_cast<const float2 *>(d.pro_stats)[c.valid ? n : 0];
+        float gmean = 0.f, grstd = 0.f;
+        if (EPI == MI_EPI_GN_GLU) {
+            const float2 st = reinterpret_cast<const float2 *>(d.gn_stats)[row];
+            gmean = st.x; grstd = st.y;
+        }
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+            // keep the epilogue of one 32x32 accumulator tile together: without the fence hipcc copies all
+            // accumulators out of the AGPR file first and the VGPR allocation (not the main loop) caps occupancy
+            __builtin_amdgcn_sched_barrier(0);
+            const int mbase = m0 + (wm * TM + a) * 32 + 4 * lh;
+            float biasr[16], auxr[16], aux2r[16];        // this tile's per-row vectors (float4 loads, L1/L2 hits)
+            load_rows16(d.bias, mbase, biasr);
+            if (EPI == MI_EPI_LINEAR && (LFLAGS & (MI_FLAG_SCALE | MI_FLAG_LN))) load_rows16(d.scale, mbase, auxr);
+            if (EPI == MI_EPI_GN_GLU) { load_rows16(d.gn_w, mbase, auxr); load_rows16(d.gn_b, mbase, aux2r); }
+            if (EPI == MI_EPI_LINEAR) {
+                // 32-bit row offsets from one 64-bit column base; for residual epilogues all 16 residual loads of
+                // the tile are issued first, so they are in flight together instead of one load -> store round
+                // trip per value
+                const size_t colbase = c.valid ? (size_t)c.b * d.y_bstride + c.p : 0;
+                float *const ycol = d.y + colbase;
+                const int cs = (int)d.y_cstride;
+                float resv[16];
+                if (LFLAGS & MI_FLAG_RES) {
+                    const float *const rcol = d.res + colbase;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = mbase + (r & 3) + 8 * (r >> 2);
+                        resv[r] = rcol[(c.valid && m < d.M) ? m * cs : 0];
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mbase + (r & 3) + 8 * (r >> 2);
+                    float v;
+                    if (LFLAGS & MI_FLAG_LN) v = lnstat.y * (acc[a][b][r] - lnstat.x * auxr[r]) + biasr[r];
+                    else v = acc[a][b][r] + biasr[r];
+                    if (LFLAGS & MI_FLAG_GELU) v = gelu_exact(v);
+                    if (LFLAGS & MI_FLAG_SCALE) v *= auxr[r];
+                    if (LFLAGS & MI_FLAG_RES) v += resv[r];
+                    // branch-free: out-of-range rows / columns are stored to a per-lane sink word
+                    *((c.valid && m < d.M) ? ycol + m * cs : sink) = v;
+                }
+            } else if (EPI == MI_EPI_GLU || EPI == MI_EPI_GN_GLU) {
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const int m = mbase + (r & 3) + 8 * (r >> 2);   // even row: value, m+1: gate
+                    float va = acc[a][b][r] + biasr[r], vg = acc[a][b][r + 1] + biasr[r + 1];
+                    if (EPI == MI_EPI_GN_GLU) {
+                        va = (va - gmean) * grstd * auxr[r] + aux2r[r];
+                        vg = (vg - gmean) * grstd * auxr[r + 1] + aux2r[r + 1];
+                    }
+                    float v = va * sigmoid_f(vg);
+                    const int ch = m >> 1;
+                    const bool ok = c.valid && m < d.M;
+                    const size_t idx = ok ? (size_t)c.b * d.y_bstride + (size_t)ch * d.y_cstride + c.p : 0;
+                    if (EPI == MI_EPI_GN_GLU) v = d.res[idx] + d.scale[ok ? ch : 0] * v;
+                    else if (d.flags & MI_FLAG_EMB) v += d.emb[ok ? ch * d.O1 + c.o1 : 0];
+                    *(ok ? d.y + idx : sink) = v;
+                }
+            } else if (EPI == MI_EPI_BIAS_STATS || EPI == MI_EPI_STATS_ONLY) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mbase + (r & 3) + 8 * (r >> 2);
+                    const float v = acc[a][b][r] + biasr[r];
+                    const bool ok = c.valid && m < d.M;
+                    if (EPI == MI_EPI_BIAS_STATS)
+                        *(ok ? d.y + ((size_t)c.b * d.y_bstride + (size_t)m * d.y_cstride + c.p) : sink) = v;
+                    s1 += ok ? v : 0.f; s2 += ok ? v * v : 0.f;
+                }
+            } else if (EPI == MI_EPI_CONVTR) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mbase + (r & 3) + 8 * (r >> 2);
+                    const int co = m >> 2, ph = m & 3;
+                    float v = acc[a][b][r] + biasr[r];
+                    if (d.flags & MI_FLAG_GELU) v = gelu_exact(v);
+                    const int o = 4 * ((d.flags & MI_FLAG_TR_FREQ) ? c.o1 : c.o2) + ph - 2;
+                    const bool ok = c.valid && m < d.M && o >= 0 && o < d.out_len;
+                    const size_t pos = (d.flags & MI_FLAG_TR_FREQ) ? (size_t)o * d.O2 + c.o2 : (size_t)o;
+                    const size_t idx = ok ? (size_t)c.b * d.y_bstride + (size_t)co * d.y_cstride + pos : 0;
+                    if (d.flags & MI_FLAG_RES) v += d.res[idx];
+                    *(ok ? d.y + idx : sink) = v;
+                }
+            }
+        }
+        if (EPI == MI_EPI_BIAS_STATS || EPI == MI_EPI_STATS_ONLY) {
+            // a wave's 32 columns span at most two statistics rows (O2 >= 32): reduce both groups
+            double t1 = (double)s1, t2 = (double)s2;
+            t1 += __shfl_xor(t1, 32); t2 += __shfl_xor(t2, 32);          // the two lane halves share a column
+            const int rid = c.valid ? row : -1;
+            const int row0 = __shfl(rid, 0);
+            int rowB = rid;
+            double a1 = (rid == row0 && rid >= 0) ? t1 : 0.0, a2 = (rid == row0 && rid >= 0) ? t2 : 0.0;
+            double b1 = (rid != row0 && rid >= 0) ? t1 : 0.0, b2 = (rid != row0 && rid >= 0) ? t2 : 0.0;
+#pragma unroll
+            for (int off = 16; off > 0; off >>= 1) {
+                a1 += __shfl_xor(a1, off); a2 += __shfl_xor(a2, off);
+                b1 += __shfl_xor(b1, off); b2 += __shfl_xor(b2, off);
+                rowB = max(rowB, __shfl_xor(rowB, off));
+            }
+            if (lane == 0 && row0 >= 0) {
+                double *dst = d.stats + ((size_t)row0 * kStatSlots + slot) * 2;
+                atomicAdd(dst, a1); atomicAdd(dst + 1, a2);
+                if (rowB != row0) {
+                    dst = d.stats + ((size_t)rowB * kStatSlots + slot) * 2;
+                    atomicAdd(dst, b1); atomicAdd(dst + 1, b2);
+                }
+            }
+        }
+    }
+}
+
 // LFLAGS: the MI_FLAG_GELU/SCALE/RES bits of a LINEAR epilogue as compile-time constants (runtime flag branches
 // inside the unrolled epilogue made hipcc copy all 64 accumulators to VGPRs at once: 204 registers, 2 waves/SIMD)
 template <int WM, int WN, int TM, int TN, int EPI, int LFLAGS, bool PLAIN>
@@ -196,130 +326,104 @@ __global__ __launch_bounds__(256, (TM * TN == 4 ? 3 : 4)) void conv_gemm_kernel(
 #undef MI_LOAD_TILE
 #undef MI_STORE_TILE
 
-    // ---- epilogue ---------------------------------------------------------------------------------
-    // acc[a][b][r] is C[m][n] with n = ncol(b) + li, m = mrow(a) + (r & 3) + 8 * (r >> 2) + 4 * lh
-    const int slot = blockIdx.x % kStatSlots;
-    float *const sink = d.sink + tid;
-#pragma unroll
-    for (int b = 0; b < TN; ++b) {
-        const int n = n0 + (wn * TN + b) * 32 + li;
-        const ColInfo c = decompose(n, N, P, d.O2, o2v);
-        const int row = d.row_mode ? c.b * d.O1 + c.o1 : c.b;
-        float s1 = 0.f, s2 = 0.f;
-        float2 lnstat = make_float2(0.f, 1.f);
-        if (EPI == MI_EPI_LINEAR && (LFLAGS & MI_FLAG_LN))
-            lnstat = reinterpret_cast<const float2 *>(d.pro_stats)[c.valid ? n : 0];
-        float gmean = 0.f, grstd = 0.f;
-        if (EPI == MI_EPI_GN_GLU) {
-            const float2 st = reinterpret_cast<const float2 *>(d.gn_stats)[row];
-            gmean = st.x; grstd = st.y;
-        }
-#pragma unroll
-        for (int a = 0; a < TM; ++a) {
-            // keep the epilogue of one 32x32 accumulator tile together: without the fence hipcc copies all
-            // accumulators out of the AGPR file first and the VGPR allocation (not the main loop) caps occupancy
-            __builtin_amdgcn_sched_barrier(0);
-            const int mbase = m0 + (wm * TM + a) * 32 + 4 * lh;
-            float biasr[16], auxr[16], aux2r[16];        // this tile's per-row vectors (float4 loads, L1/L2 hits)
-            load_rows16(d.bias, mbase, biasr);
-            if (EPI == MI_EPI_LINEAR && (LFLAGS & (MI_FLAG_SCALE | MI_FLAG_LN))) load_rows16(d.scale, mbase, auxr);
-            if (EPI == MI_EPI_GN_GLU) { load_rows16(d.gn_w, mbase, auxr); load_rows16(d.gn_b, mbase, aux2r); }
-            if (EPI == MI_EPI_LINEAR) {
-                // 32-bit row offsets from one 64-bit column base; for residual epilogues all 16 residual loads of
-                // the tile are issued first, so they are in flight together instead of one load -> store round
-                // trip per value
-                const size_t colbase = c.valid ? (size_t)c.b * d.y_bstride + c.p : 0;
-                float *const ycol = d.y + colbase;
-                const int cs = (int)d.y_cstride;
-                float resv[16];
-                if (LFLAGS & MI_FLAG_RES) {
-                    const float *const rcol = d.res + colbase;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int m = mbase + (r & 3) + 8 * (r >> 2);
-                        resv[r] = rcol[(c.valid && m < d.M) ? m * cs : 0];
-                    }
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = mbase + (r & 3) + 8 * (r >> 2);
-                    float v;
-                    if (LFLAGS & MI_FLAG_LN) v = lnstat.y * (acc[a][b][r] - lnstat.x * auxr[r]) + biasr[r];
-                    else v = acc[a][b][r] + biasr[r];
-                    if (LFLAGS & MI_FLAG_GELU) v = gelu_exact(v);
-                    if (LFLAGS & MI_FLAG_SCALE) v *= auxr[r];
-                    if (LFLAGS & MI_FLAG_RES) v += resv[r];
-                    // branch-free: out-of-range rows / columns are stored to a per-lane sink word
-                    *((c.valid && m < d.M) ? ycol + m * cs : sink) = v;
-                }
-            } else if (EPI == MI_EPI_GLU || EPI == MI_EPI_GN_GLU) {
-#pragma unroll
-                for (int r = 0; r < 16; r += 2) {
-                    const int m = mbase + (r & 3) + 8 * (r >> 2);   // even row: value, m+1: gate
-                    float va = acc[a][b][r] + biasr[r], vg = acc[a][b][r + 1] + biasr[r + 1];
-                    if (EPI == MI_EPI_GN_GLU) {
-                        va = (va - gmean) * grstd * auxr[r] + aux2r[r];
-                        vg = (vg - gmean) * grstd * auxr[r + 1] + aux2r[r + 1];
-                    }
-                    float v = va * sigmoid_f(vg);
-                    const int ch = m >> 1;
-                    const bool ok = c.valid && m < d.M;
-                    const size_t idx = ok ? (size_t)c.b * d.y_bstride + (size_t)ch * d.y_cstride + c.p : 0;
-                    if (EPI == MI_EPI_GN_GLU) v = d.res[idx] + d.scale[ok ? ch : 0] * v;
-                    else if (d.flags & MI_FLAG_EMB) v += d.emb[ok ? ch * d.O1 + c.o1 : 0];
-                    *(ok ? d.y + idx : sink) = v;
-                }
-            } else if (EPI == MI_EPI_BIAS_STATS || EPI == MI_EPI_STATS_ONLY) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = mbase + (r & 3) + 8 * (r >> 2);
-                    const float v = acc[a][b][r] + biasr[r];
-                    const bool ok = c.valid && m < d.M;
-                    if (EPI == MI_EPI_BIAS_STATS)
-                        *(ok ? d.y + ((size_t)c.b * d.y_bstride + (size_t)m * d.y_cstride + c.p) : sink) = v;
-                    s1 += ok ? v : 0.f; s2 += ok ? v * v : 0.f;
-                }
-            } else if (EPI == MI_EPI_CONVTR) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = mbase + (r & 3) + 8 * (r >> 2);
-                    const int co = m >> 2, ph = m & 3;
-                    float v = acc[a][b][r] + biasr[r];
-                    if (d.flags & MI_FLAG_GELU) v = gelu_exact(v);
-                    const int o = 4 * ((d.flags & MI_FLAG_TR_FREQ) ? c.o1 : c.o2) + ph - 2;
-                    const bool ok = c.valid && m < d.M && o >= 0 && o < d.out_len;
-                    const size_t pos = (d.flags & MI_FLAG_TR_FREQ) ? (size_t)o * d.O2 + c.o2 : (size_t)o;
-                    const size_t idx = ok ? (size_t)c.b * d.y_bstride + (size_t)co * d.y_cstride + pos : 0;
-                    if (d.flags & MI_FLAG_RES) v += d.res[idx];
-                    *(ok ? d.y + idx : sink) = v;
-                }
-            }
-        }
-        if (EPI == MI_EPI_BIAS_STATS || EPI == MI_EPI_STATS_ONLY) {
-            // a wave's 32 columns span at most two statistics rows (O2 >= 32): reduce both groups
-            double t1 = (double)s1, t2 = (double)s2;
-            t1 += __shfl_xor(t1, 32); t2 += __shfl_xor(t2, 32);          // the two lane halves share a column
-            const int rid = c.valid ? row : -1;
-            const int row0 = __shfl(rid, 0);
-            int rowB = rid;
-            double a1 = (rid == row0 && rid >= 0) ? t1 : 0.0, a2 = (rid == row0 && rid >= 0) ? t2 : 0.0;
-            double b1 = (rid != row0 && rid >= 0) ? t1 : 0.0, b2 = (rid != row0 && rid >= 0) ? t2 : 0.0;
-#pragma unroll
-            for (int off = 16; off > 0; off >>= 1) {
-                a1 += __shfl_xor(a1, off); a2 += __shfl_xor(a2, off);
-                b1 += __shfl_xor(b1, off); b2 += __shfl_xor(b2, off);
-                rowB = max(rowB, __shfl_xor(rowB, off));
-            }
-            if (lane == 0 && row0 >= 0) {
-                double *dst = d.stats + ((size_t)row0 * kStatSlots + slot) * 2;
-                atomicAdd(dst, a1); atomicAdd(dst + 1, a2);
-                if (rowB != row0) {
-                    dst = d.stats + ((size_t)rowB * kStatSlots + slot) * 2;
-                    atomicAdd(dst, b1); atomicAdd(dst + 1, b2);
-                }
-            }
-        }
+    conv_epilogue<TM, TN, EPI, LFLAGS>(d, acc, m0, n0, wm, wn, N, P, o2v);
+}
+
+// ---------------------------------------------------------------------------------------------
+// LDS-DMA main loop for the plain (1x1 / linear) 128 x 128 tile: both operand tiles go global -> LDS with
+// global_load_lds_dwordx4 (no staging registers, no ds_write), a 3-stage LDS ring keeps TWO K tiles in flight
+// behind a counted s_waitcnt vmcnt(4) and ONE raw s_barrier per K tile (cdna_hip_programming.md: "Pipelining
+// across barriers").  Each wave-instruction lands 1 KiB = two 128-float rows of a [16][128] tile image.
+typedef __attribute__((address_space(1))) const void gvoid_t;
+typedef __attribute__((address_space(3))) void lvoid_t;
+
+template <int EPI, int LFLAGS>
+__global__ __launch_bounds__(256, 3) void conv_gemm_dma_kernel(const mi_conv_desc d, const int N, const int MT) {
+    constexpr int TM = 2, TN = 2, WN = 2, BM = 128;
+    constexpr int SS = BK * (BM + BN);                       // floats per stage: A image then B image
+    __shared__ __attribute__((aligned(16))) float smem[3 * SS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    int mt, nt;
+    {
+        const int NT = gridDim.x / MT, full = (NT / 8) * 8;
+        const int id = blockIdx.x, per8 = 8 * MT;
+        if (id < full * MT) { const int g = id / per8, r = id - g * per8; nt = g * 8 + (r & 7); mt = r >> 3; }
+        else { const int r = id - full * MT; mt = r % MT; nt = full + r / MT; }
     }
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int P = d.O1 * d.O2;
+    const int o2v = d.o2_valid ? d.o2_valid : d.O2;
+
+    // this lane's share of every tile: rows 4*wave + 2*j + (lane >> 5), j = 0, 1; 16 bytes at column 4*(lane & 31)
+    const int r0 = 4 * wave + (lane >> 5), c4 = (lane & 31) * 4;
+    const float *asrc = d.wt + (size_t)r0 * d.Mpad + m0 + c4;
+    const size_t a_row2 = (size_t)2 * d.Mpad, a_step = (size_t)BK * d.Mpad;
+    const ColInfo lc = decompose(n0 + c4, N, P, d.O2, d.O2);
+    const float *bsrc = lc.valid ? d.x + (size_t)lc.b * d.x_bstride + lc.p + (size_t)r0 * P : d.sink + 256;
+    const size_t b_row2 = lc.valid ? (size_t)2 * P : 0, b_step = lc.valid ? (size_t)BK * P : 0;
+
+#define MI_DMA_TILE(kt, stage)                                                                                  \
+    do {                                                                                                        \
+        float *sa = smem + (stage) * SS + (4 * wave) * BM, *sb = smem + (stage) * SS + BK * BM + (4 * wave) * BN; \
+        const float *ga = asrc + (size_t)(kt) * a_step, *gb = bsrc + (size_t)(kt) * b_step;                      \
+        __builtin_amdgcn_global_load_lds((gvoid_t *)ga, (lvoid_t *)sa, 16, 0, 0);                                \
+        __builtin_amdgcn_global_load_lds((gvoid_t *)(ga + a_row2), (lvoid_t *)(sa + 2 * BM), 16, 0, 0);          \
+        __builtin_amdgcn_global_load_lds((gvoid_t *)gb, (lvoid_t *)sb, 16, 0, 0);                                \
+        __builtin_amdgcn_global_load_lds((gvoid_t *)(gb + b_row2), (lvoid_t *)(sb + 2 * BN), 16, 0, 0);          \
+    } while (0)
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int nk = d.Kpad / BK;
+    const int li = lane & 31, lh = lane >> 5;
+    MI_DMA_TILE(0, 0);
+    if (nk > 1) MI_DMA_TILE(1, 1);
+    int stage = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        // tile kt has landed once all but this wave's newest tile (4 instructions) are done -- for every wave
+        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        // stage (kt+2)%3 == (kt-1)%3 was last read in the previous iteration, which every wave has finished
+        if (kt + 2 < nk) MI_DMA_TILE(kt + 2, stage == 0 ? 2 : stage - 1);
+        const float *As = smem + stage * SS, *Bs = As + BK * BM;
+        float af[2][TM], bf[2][TN];
+#pragma unroll
+        for (int a = 0; a < TM; ++a) af[0][a] = As[lh * BM + (wm * TM + a) * 32 + li];
+#pragma unroll
+        for (int b = 0; b < TN; ++b) bf[0][b] = Bs[lh * BN + (wn * TN + b) * 32 + li];
+#pragma unroll
+        for (int s = 0; s < BK / 2; ++s) {
+            if (s + 1 < BK / 2) {
+#pragma unroll
+                for (int a = 0; a < TM; ++a) af[(s + 1) & 1][a] = As[(2 * (s + 1) + lh) * BM + (wm * TM + a) * 32 + li];
+#pragma unroll
+                for (int b = 0; b < TN; ++b) bf[(s + 1) & 1][b] = Bs[(2 * (s + 1) + lh) * BN + (wn * TN + b) * 32 + li];
+            }
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s & 1][a], bf[s & 1][b], acc[a][b], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+        for (int s = 0; s < BK / 2; ++s) {
+            if (s + 1 < BK / 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
+        }
+        stage = stage == 2 ? 0 : stage + 1;
+    }
+#undef MI_DMA_TILE
+    conv_epilogue<TM, TN, EPI, LFLAGS>(d, acc, m0, n0, wm, wn, N, P, o2v);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -330,6 +434,14 @@ static int launch_cfg(const mi_conv_desc &d, hipStream_t st) {
     MI_REQUIRE(N64 < (1ll << 31) - 256, "conv: too many output positions (%lld)", (long long)N64);
     MI_REQUIRE(d.Mpad % BM == 0, "conv: Mpad %d not a multiple of the %d-row tile", d.Mpad, BM);
     const int N = (int)N64, MT = d.Mpad / BM, NT = ceil_div(N, BN);
+    if constexpr (PLAIN && BM == 128 && EPI == MI_EPI_LINEAR) {
+        static const bool use_dma = getenv("MI_NO_DMA") == nullptr;
+        if (use_dma) {
+            hipLaunchKernelGGL((conv_gemm_dma_kernel<EPI, LFLAGS>), dim3((unsigned)MT * NT), dim3(256), 0, st, d, N, MT);
+            MI_CHECK_LAUNCH();
+            return MI_OK;
+        }
+    }
     hipLaunchKernelGGL((conv_gemm_kernel<WM, WN, TM, TN, EPI, LFLAGS, PLAIN>), dim3((unsigned)MT * NT), dim3(256), 0, st, d, N, MT);
     MI_CHECK_LAUNCH();
     return MI_OK;
@@ -356,9 +468,13 @@ int conv_pick_tile(int M) {
 }
 
 // 256-float dump for the epilogue's out-of-range stores (one word per thread), shared by all launches
+// ... followed by 64 floats that stay zero (source of the LDS-DMA loader for out-of-range columns)
 static float *conv_sink() {
     static float *p = nullptr;
-    if (!p && hipMalloc((void **)&p, 256 * sizeof(float)) != hipSuccess) p = nullptr;
+    if (!p) {
+        if (hipMalloc((void **)&p, 320 * sizeof(float)) != hipSuccess) { p = nullptr; return nullptr; }
+        (void)hipMemset(p, 0, 320 * sizeof(float));
+    }
     return p;
 }
 
