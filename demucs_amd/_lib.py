@@ -44,7 +44,7 @@ class MiConvDesc(C.Structure):
         ("y", C.c_void_p), ("y_bstride", C.c_int64), ("y_cstride", C.c_int64),
         ("stats", C.c_void_p), ("gn_stats", C.c_void_p), ("gn_w", C.c_void_p), ("gn_b", C.c_void_p),
         ("out_len", C.c_int32), ("tile_m", C.c_int32), ("plain", C.c_int32), ("reserved", C.c_int32),
-        ("o2_valid", C.c_int32), ("reserved2", C.c_int32), ("sink", C.c_void_p),
+        ("o2_valid", C.c_int32), ("reserved2", C.c_int32), ("sink", C.c_void_p), ("wx", C.c_void_p),
     ]
 
 
@@ -67,6 +67,7 @@ SIGNATURES = {
     "mi_stft_cac": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "mi_istft_cac": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "mi_conv_forward": (C.c_int, [C.POINTER(MiConvDesc), C.c_void_p]),
+    "mi_conv_pack_split": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "mi_attention": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_void_p]),
     "mi_gn_gelu": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,

@@ -75,6 +75,8 @@ typedef struct mi_conv_desc {
                                not a multiple of 4 keep 16-byte aligned starts and use the float4 loader            */
     int32_t reserved2;
     float *sink;            /* >= 256 floats that out-of-range epilogue stores are diverted to; NULL = library-owned */
+    const void *wx;         /* NULL, or the weights as the split-bf16 tile image of mi_conv_pack_split for THIS tile_m:
+                               selects the 6-product bf16 MFMA main loop (gemm_x6.hip) for tile_m 64 / 96 / 128     */
 } mi_conv_desc;
 
 #ifdef __cplusplus

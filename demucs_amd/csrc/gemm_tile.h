@@ -1,0 +1,182 @@
+// Device-side pieces shared by the implicit-GEMM main loops (gemm_conv.hip: fp32 MFMA; gemm_x6.hip: split-bf16
+// MFMA): tile constants, output-column decomposition, the table-driven gather and the fused epilogues.
+#pragma once
+#include "common.h"
+#include "gemm_conv.h"
+#include "kernels.h"
+
+namespace mi {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 16;
+constexpr int BN = 128;
+
+struct ColInfo {   // decomposition of one output column n = (b, o1, o2)
+    int b, o1, o2, p;
+    bool valid;
+};
+
+__device__ __forceinline__ ColInfo decompose(int n, int N, int P, int O2, int o2v) {
+    ColInfo c;
+    c.valid = n < N;
+    const int nn = c.valid ? n : 0;
+    c.b = nn / P;
+    c.p = nn - c.b * P;
+    c.o1 = c.p / O2;
+    c.o2 = c.p - c.o1 * O2;
+    c.valid = c.valid && c.o2 < o2v;       // o2v < O2: O2 is a padded row pitch
+    return c;
+}
+
+// the 16 rows a lane owns in one 32x32 accumulator tile are 4 groups of 4 consecutive rows: fetch a per-row
+// vector (bias, scale, GroupNorm affine) for them with 4 float4 loads instead of 16 dependent dword loads
+__device__ __forceinline__ void load_rows16(const float *p, int mbase, float (&out)[16]) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float4 v = *reinterpret_cast<const float4 *>(p + mbase + 8 * g);
+        out[4 * g] = v.x; out[4 * g + 1] = v.y; out[4 * g + 2] = v.z; out[4 * g + 3] = v.w;
+    }
+}
+
+// B-operand gather for one element: branch-free (invalid taps read x[0] and are zeroed by a select)
+__device__ __forceinline__ float gather_b(const mi_conv_desc &d, const mi_ktab_entry e, const float *xcol, int i1b, int i2b,
+                                          bool colvalid, bool &ok) {
+    const int i1 = i1b + e.d1, i2 = i2b + e.d2;
+    ok = colvalid && (unsigned)i1 < (unsigned)d.D1 && (unsigned)i2 < (unsigned)d.D2;
+    const float *p = ok ? xcol + e.off : d.x;
+    return *p;
+}
+
+// PLAIN = 1x1 / linear layer with K % 16 == 0 and (O1*O2) % 4 == 0: no gather table, float4 activation loads.
+// Epilogue shared by the register-staged and the LDS-DMA main loops.
+// acc[a][b][r] is C[m][n] with n = n0 + (wn*TN + b)*32 + li, m = m0 + (wm*TM + a)*32 + (r & 3) + 8 * (r >> 2) + 4 * lh
+template <int TM, int TN, int EPI, int LFLAGS>
+__device__ __forceinline__ void conv_epilogue(const mi_conv_desc &d, f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int N,
+                                              int P, int o2v) {
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+    const int slot = blockIdx.x % kStatSlots;
+    float *const sink = d.sink + tid;
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+        const int n = n0 + (wn * TN + b) * 32 + li;
+        const ColInfo c = decompose(n, N, P, d.O2, o2v);
+        const int row = d.row_mode ? c.b * d.O1 + c.o1 : c.b;
+        float s1 = 0.f, s2 = 0.f;
+        float2 lnstat = make_float2(0.f, 1.f);
+        if (EPI == MI_EPI_LINEAR && (LFLAGS & MI_FLAG_LN))
+            lnstat = reinterpret_cast<const float2 *>(d.pro_stats)[c.valid ? n : 0];
+        float gmean = 0.f, grstd = 0.f;
+        if (EPI == MI_EPI_GN_GLU) {
+            const float2 st = reinterpret_cast<const float2 *>(d.gn_stats)[row];
+            gmean = st.x; grstd = st.y;
+        }
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+            // keep the epilogue of one 32x32 accumulator tile together: without the fence hipcc copies all
+            // accumulators out of the AGPR file first and the VGPR allocation (not the main loop) caps occupancy
+            __builtin_amdgcn_sched_barrier(0);
+            const int mbase = m0 + (wm * TM + a) * 32 + 4 * lh;
+            float biasr[16], auxr[16], aux2r[16];        // this tile's per-row vectors (float4 loads, L1/L2 hits)
+            load_rows16(d.bias, mbase, biasr);
+            if (EPI == MI_EPI_LINEAR && (LFLAGS & (MI_FLAG_SCALE | MI_FLAG_LN))) load_rows16(d.scale, mbase, auxr);
+            if (EPI == MI_EPI_GN_GLU) { load_rows16(d.gn_w, mbase, auxr); load_rows16(d.gn_b, mbase, aux2r); }
+            if (EPI == MI_EPI_LINEAR) {
+                // 32-bit row offsets from one 64-bit column base; for residual epilogues all 16 residual loads of
+                // the tile are issued first, so they are in flight together instead of one load -> store round
+                // trip per value
+                const size_t colbase = c.valid ? (size_t)c.b * d.y_bstride + c.p : 0;
+                float *const ycol = d.y + colbase;
+                const int cs = (int)d.y_cstride;
+                float resv[16];
+                if (LFLAGS & MI_FLAG_RES) {
+                    const float *const rcol = d.res + colbase;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = mbase + (r & 3) + 8 * (r >> 2);
+                        resv[r] = rcol[(c.valid && m < d.M) ? m * cs : 0];
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mbase + (r & 3) + 8 * (r >> 2);
+                    float v;
+                    if (LFLAGS & MI_FLAG_LN) v = lnstat.y * (acc[a][b][r] - lnstat.x * auxr[r]) + biasr[r];
+                    else v = acc[a][b][r] + biasr[r];
+                    if (LFLAGS & MI_FLAG_GELU) v = gelu_exact(v);
+                    if (LFLAGS & MI_FLAG_SCALE) v *= auxr[r];
+                    if (LFLAGS & MI_FLAG_RES) v += resv[r];
+                    // branch-free: out-of-range rows / columns are stored to a per-lane sink word
+                    *((c.valid && m < d.M) ? ycol + m * cs : sink) = v;
+                }
+            } else if (EPI == MI_EPI_GLU || EPI == MI_EPI_GN_GLU) {
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const int m = mbase + (r & 3) + 8 * (r >> 2);   // even row: value, m+1: gate
+                    float va = acc[a][b][r] + biasr[r], vg = acc[a][b][r + 1] + biasr[r + 1];
+                    if (EPI == MI_EPI_GN_GLU) {
+                        va = (va - gmean) * grstd * auxr[r] + aux2r[r];
+                        vg = (vg - gmean) * grstd * auxr[r + 1] + aux2r[r + 1];
+                    }
+                    float v = va * sigmoid_f(vg);
+                    const int ch = m >> 1;
+                    const bool ok = c.valid && m < d.M;
+                    const size_t idx = ok ? (size_t)c.b * d.y_bstride + (size_t)ch * d.y_cstride + c.p : 0;
+                    if (EPI == MI_EPI_GN_GLU) v = d.res[idx] + d.scale[ok ? ch : 0] * v;
+                    else if (d.flags & MI_FLAG_EMB) v += d.emb[ok ? ch * d.O1 + c.o1 : 0];
+                    *(ok ? d.y + idx : sink) = v;
+                }
+            } else if (EPI == MI_EPI_BIAS_STATS || EPI == MI_EPI_STATS_ONLY) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mbase + (r & 3) + 8 * (r >> 2);
+                    const float v = acc[a][b][r] + biasr[r];
+                    const bool ok = c.valid && m < d.M;
+                    if (EPI == MI_EPI_BIAS_STATS)
+                        *(ok ? d.y + ((size_t)c.b * d.y_bstride + (size_t)m * d.y_cstride + c.p) : sink) = v;
+                    s1 += ok ? v : 0.f; s2 += ok ? v * v : 0.f;
+                }
+            } else if (EPI == MI_EPI_CONVTR) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mbase + (r & 3) + 8 * (r >> 2);
+                    const int co = m >> 2, ph = m & 3;
+                    float v = acc[a][b][r] + biasr[r];
+                    if (d.flags & MI_FLAG_GELU) v = gelu_exact(v);
+                    const int o = 4 * ((d.flags & MI_FLAG_TR_FREQ) ? c.o1 : c.o2) + ph - 2;
+                    const bool ok = c.valid && m < d.M && o >= 0 && o < d.out_len;
+                    const size_t pos = (d.flags & MI_FLAG_TR_FREQ) ? (size_t)o * d.O2 + c.o2 : (size_t)o;
+                    const size_t idx = ok ? (size_t)c.b * d.y_bstride + (size_t)co * d.y_cstride + pos : 0;
+                    if (d.flags & MI_FLAG_RES) v += d.res[idx];
+                    *(ok ? d.y + idx : sink) = v;
+                }
+            }
+        }
+        if (EPI == MI_EPI_BIAS_STATS || EPI == MI_EPI_STATS_ONLY) {
+            // a wave's 32 columns span at most two statistics rows (O2 >= 32): reduce both groups
+            double t1 = (double)s1, t2 = (double)s2;
+            t1 += __shfl_xor(t1, 32); t2 += __shfl_xor(t2, 32);          // the two lane halves share a column
+            const int rid = c.valid ? row : -1;
+            const int row0 = __shfl(rid, 0);
+            int rowB = rid;
+            double a1 = (rid == row0 && rid >= 0) ? t1 : 0.0, a2 = (rid == row0 && rid >= 0) ? t2 : 0.0;
+            double b1 = (rid != row0 && rid >= 0) ? t1 : 0.0, b2 = (rid != row0 && rid >= 0) ? t2 : 0.0;
+#pragma unroll
+            for (int off = 16; off > 0; off >>= 1) {
+                a1 += __shfl_xor(a1, off); a2 += __shfl_xor(a2, off);
+                b1 += __shfl_xor(b1, off); b2 += __shfl_xor(b2, off);
+                rowB = max(rowB, __shfl_xor(rowB, off));
+            }
+            if (lane == 0 && row0 >= 0) {
+                double *dst = d.stats + ((size_t)row0 * kStatSlots + slot) * 2;
+                atomicAdd(dst, a1); atomicAdd(dst + 1, a2);
+                if (rowB != row0) {
+                    dst = d.stats + ((size_t)rowB * kStatSlots + slot) * 2;
+                    atomicAdd(dst, b1); atomicAdd(dst + 1, b2);
+                }
+            }
+        }
+    }
+}
+
+}  // namespace mi

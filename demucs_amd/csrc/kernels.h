@@ -55,6 +55,10 @@ int launch_dconv_row(const DConvRowArgs &a, int C, int rows, hipStream_t st);
 // gemm_conv.hip
 int launch_conv(const mi_conv_desc &d, hipStream_t st);
 int conv_pick_tile(int M);
+// gemm_x6.hip
+bool conv_x6_supported(int tile);
+int launch_conv_x6(const mi_conv_desc &d, int tile, bool plain, hipStream_t st);
+int launch_pack_split(const float *wt, int Kpad, int Mpad, int tile_m, void *wx, hipStream_t st);
 
 // attention.hip
 int launch_attention(const float *q, const float *k, const float *v, float *o, int B, int heads, int Tq, int Tk, int64_t q_bs,

@@ -164,6 +164,17 @@ static std::vector<mi_ktab_entry> build_ktab(const Gather &g, int Kpad) {
     return tab;
 }
 
+// Second copy of the packed weights as exact 3-term bf16 tile images: selects the 6-product bf16 MFMA main loop.
+// MI_FP32_MFMA=1 keeps every layer on the native fp32 MFMA kernels (A/B comparisons, bisecting).
+int Model::pack_split(PackedConv *pc) {
+    static const bool fp32_only = getenv("MI_FP32_MFMA") != nullptr;
+    if (fp32_only || !conv_x6_supported(pc->tile)) return MI_OK;
+    MI_TRY(dev_alloc(&pc->wx, (size_t)6 * pc->Kpad * pc->Mpad));
+    MI_TRY(launch_pack_split(pc->wt, pc->Kpad, pc->Mpad, pc->tile, pc->wx, nullptr));
+    MI_HIP(hipStreamSynchronize(nullptr));
+    return MI_OK;
+}
+
 // Conv / Linear weights W[M][K] (K = Cin*K1*K2 flattened) -> Wt[Kpad][Mpad]; `glu` interleaves the
 // two GLU halves: packed row 2c = W[c], 2c+1 = W[c + M/2].
 int Model::pack_conv(const float *W, const float *bias, int M, int K, bool glu, PackedConv *pc) {
@@ -177,7 +188,7 @@ int Model::pack_conv(const float *W, const float *bias, int M, int K, bool glu, 
     }
     MI_TRY(upload(wt, &pc->wt));
     MI_TRY(upload(b, &pc->bias));
-    return MI_OK;
+    return pack_split(pc);
 }
 
 // ConvTranspose(k=8, s=4) weights W[Cin][Cout][8] -> 4-phase GEMM: row m = 4*co + r, k = 2*ci + j,
@@ -196,7 +207,7 @@ int Model::pack_convtr(const float *W, const float *bias, int Cin, int Cout, Pac
         for (int r = 0; r < 4; ++r) b[4 * co + r] = bias[co];
     MI_TRY(upload(wt, &pc->wt));
     MI_TRY(upload(b, &pc->bias));
-    return MI_OK;
+    return pack_split(pc);
 }
 
 // Linear layer applied to LayerNorm(x): fold the LayerNorm affine into the weights (MI_FLAG_LN in gemm_conv.h)
@@ -546,7 +557,7 @@ struct Geo {          // geometry of one activation tensor family
 static mi_conv_desc base_desc(const PackedConv &pc, const mi_ktab_entry *ktab, const float *x, int64_t x_bs, const Geo &g) {
     mi_conv_desc d;
     memset(&d, 0, sizeof(d));
-    d.wt = pc.wt; d.M = pc.M; d.Mpad = pc.Mpad; d.K = pc.K; d.Kpad = pc.Kpad; d.ktab = ktab; d.bias = pc.bias; d.tile_m = pc.tile;
+    d.wt = pc.wt; d.M = pc.M; d.Mpad = pc.Mpad; d.K = pc.K; d.Kpad = pc.Kpad; d.ktab = ktab; d.bias = pc.bias; d.tile_m = pc.tile; d.wx = pc.wx;
     d.x = x; d.x_bstride = x_bs; d.B = g.B; d.D1 = g.D1; d.D2 = g.D2; d.O1 = g.D1; d.O2 = g.pitch(); d.S1 = 1; d.S2 = 1;
     d.o2_valid = g.pitch() != g.D2 ? g.D2 : 0;       // enumerate the padded row, mask the padding columns
     d.row_mode = g.row_mode;

@@ -132,6 +132,13 @@ int mi_istft_cac(const float *x_dev, int32_t B, int32_t S, int32_t L, float *wav
 struct mi_conv_desc;
 int mi_conv_forward(const struct mi_conv_desc *desc, void *stream);
 
+/* Re-packs fp32 weights Wt[Kpad][Mpad] (the mi_conv_desc.wt layout) into the split-bf16 tile image
+ *   [Mpad/tile_m][Kpad/16][3 terms][2 k-halves][tile_m][8] bf16 (6 * Kpad * Mpad bytes) that mi_conv_desc.wx takes:
+ *   each weight w = hi + mid + lo exactly, so the 6-product bf16 MFMA loop reproduces the fp32 product sum
+ *   (no reference counterpart: it is the load-time half of how F.conv / F.linear run on the matrix cores).
+ *   tile_m must be the tile the layer will run with (64, 96 or 128). */
+int mi_conv_pack_split(const float *wt_dev, int32_t Kpad, int32_t Mpad, int32_t tile_m, void *wx_dev, void *stream);
+
 /* Multi-head attention core softmax(QK^T/sqrt(64))V on channel-first tensors (stands in for the
  *   attention inside nn.MultiheadAttention, called at demucs/transformer.py:418-419,506):
  *   q_dev (B, heads*64, Tq) with row stride q_ld..., see demucs_amd/csrc/attention.h. */

@@ -15,6 +15,7 @@ SLOTS = 32
 def pick_tile(M):
     if M <= 32: return 32
     if M <= 64: return 64
+    if M % 128 == 0 and M % 96 == 0 and (M // 128) % 4 != 0 and (M // 96) % 4 == 0: return 96
     if M % 128 == 0: return 128
     if M % 96 == 0: return 96
     if M <= 96: return 96
@@ -70,6 +71,12 @@ def conv_call(**kw):
     """Fill a MiConvDesc from keyword arguments (tensors -> data_ptr) and launch."""
     d = _lib.MiConvDesc()
     keep = []
+    if kw.pop("x6", False) and kw.get("tile_m") in (64, 96, 128):
+        # split-bf16 image of the same packed weights: selects the 6-product bf16 MFMA main loop
+        wx = torch.empty(6 * kw["Kpad"] * kw["Mpad"], dtype=torch.uint8, device="cuda")
+        _lib.check(_lib.load().mi_conv_pack_split(kw["wt"].data_ptr(), kw["Kpad"], kw["Mpad"], kw["tile_m"], wx.data_ptr(),
+                                                  C.c_void_p(_lib.current_stream_ptr())), "mi_conv_pack_split")
+        kw["wx"] = wx
     for name, _ in _lib.MiConvDesc._fields_:
         v = kw.get(name, 0)
         if isinstance(v, torch.Tensor):

@@ -75,7 +75,13 @@ from gpu_helpers import (EPI_BIAS_STATS, EPI_CONVTR, EPI_GLU, EPI_GN_GLU, EPI_LI
                          FLAG_GELU, FLAG_RES, FLAG_SCALE, FLAG_TR_FREQ, SLOTS, conv_call, ktab, maxerr, pack_vec, pack_w)
 
 
-def test_conv_freq_strided_gelu(lib):
+@pytest.fixture(params=[False, True], ids=["fp32mfma", "bf16x6"])
+def x6(request):
+    """Both GEMM main loops: native fp32 MFMA and the exact 3-term bf16 split with 6 products (gemm_x6.hip)."""
+    return request.param
+
+
+def test_conv_freq_strided_gelu(lib, x6):
     """HEncLayer conv on the frequency axis: Conv2d k=(8,1) s=(4,1) p=(2,0) + GELU (hdemucs.py:110,136,144)."""
     B, Cin, Cout, Fr, T = 2, 12, 96, 64, 48
     x, W, b = rnd(B, Cin, Fr, T, seed=2), rnd(Cout, Cin, 8, 1, seed=3, scale=0.1), rnd(Cout, seed=4)
@@ -84,13 +90,13 @@ def test_conv_freq_strided_gelu(lib):
     kt = ktab(Cin, 8, 1, 1, 1, 2, 0, Fr * T, T, Kpad)
     y = torch.empty(B, Cout, Fr // 4, T, device="cuda")
     P = Fr // 4 * T
-    conv_call(wt=wt, M=M, Mpad=Mpad, K=K, Kpad=Kpad, ktab=kt, x=x.float().cuda(), x_bstride=Cin * Fr * T, B=B, D1=Fr, D2=T,
+    conv_call(x6=x6, wt=wt, M=M, Mpad=Mpad, K=K, Kpad=Kpad, ktab=kt, x=x.float().cuda(), x_bstride=Cin * Fr * T, B=B, D1=Fr, D2=T,
               O1=Fr // 4, O2=T, S1=4, S2=1, row_mode=1, epi=EPI_LINEAR, flags=FLAG_GELU, bias=bias, y=y, y_bstride=Cout * P,
               y_cstride=P, tile_m=tile)
     assert maxerr(y, want) < 2e-5
 
 
-def test_conv_time_strided_ragged(lib):
+def test_conv_time_strided_ragged(lib, x6):
     """HEncLayer conv on the time axis with a length that is not a multiple of the stride
     (right zero padding, hdemucs.py:132-136): L=5375 -> 1344."""
     B, Cin, Cout, L = 2, 6, 48, 5375
@@ -100,12 +106,12 @@ def test_conv_time_strided_ragged(lib):
     wt, bias, M, Mpad, K, Kpad, tile = pack_w(W.reshape(Cout, -1), b)
     kt = ktab(Cin, 1, 8, 1, 1, 0, 2, L, L, Kpad)
     y = torch.empty(B, Cout, Lo, device="cuda")
-    conv_call(wt=wt, M=M, Mpad=Mpad, K=K, Kpad=Kpad, ktab=kt, x=x.float().cuda(), x_bstride=Cin * L, B=B, D1=1, D2=L, O1=1, O2=Lo,
+    conv_call(x6=x6, wt=wt, M=M, Mpad=Mpad, K=K, Kpad=Kpad, ktab=kt, x=x.float().cuda(), x_bstride=Cin * L, B=B, D1=1, D2=L, O1=1, O2=Lo,
               S1=1, S2=4, epi=EPI_LINEAR, bias=bias, y=y, y_bstride=Cout * Lo, y_cstride=Lo, tile_m=tile)
     assert maxerr(y, want) < 2e-5
 
 
-def test_conv_3x3_glu_and_emb(lib):
+def test_conv_3x3_glu_and_emb(lib, x6):
     """HDecLayer rewrite Conv2d 3x3 + GLU (hdemucs.py:294,313), plus the additive per-(c, fr) table."""
     B, C, Fr, T = 1, 24, 16, 80
     x, W, b = rnd(B, C, Fr, T, seed=8), rnd(2 * C, C, 3, 3, seed=9, scale=0.1), rnd(2 * C, seed=10)
@@ -115,13 +121,13 @@ def test_conv_3x3_glu_and_emb(lib):
     kt = ktab(C, 3, 3, 1, 1, 1, 1, Fr * T, T, Kpad)
     y = torch.empty(B, C, Fr, T, device="cuda")
     P = Fr * T
-    conv_call(wt=wt, M=M, Mpad=Mpad, K=K, Kpad=Kpad, ktab=kt, x=x.float().cuda(), x_bstride=C * P, B=B, D1=Fr, D2=T, O1=Fr, O2=T,
+    conv_call(x6=x6, wt=wt, M=M, Mpad=Mpad, K=K, Kpad=Kpad, ktab=kt, x=x.float().cuda(), x_bstride=C * P, B=B, D1=Fr, D2=T, O1=Fr, O2=T,
               S1=1, S2=1, row_mode=1, epi=EPI_GLU, flags=FLAG_EMB, emb=emb.float().cuda().contiguous(), bias=bias, y=y,
               y_bstride=C * P, y_cstride=P, tile_m=tile)
     assert maxerr(y, want) < 2e-5
 
 
-def test_linear_scale_residual_big_k(lib):
+def test_linear_scale_residual_big_k(lib, x6):
     """nn.Linear on channel-first tokens with LayerScale + residual epilogue (transformer.py:364-367):
     M=512, K=2048 exercises the 128-row tile and a long contraction."""
     B, M, K, Tn = 2, 512, 2048, 300
@@ -131,14 +137,14 @@ def test_linear_scale_residual_big_k(lib):
     wt, bias, M_, Mpad, K_, Kpad, tile = pack_w(W, b)
     kt = ktab(K, 1, 1, 1, 1, 0, 0, Tn, Tn, Kpad)
     y = torch.empty(B, M, Tn, device="cuda")
-    conv_call(wt=wt, M=M, Mpad=Mpad, K=K, Kpad=Kpad, ktab=kt, x=x.float().cuda(), x_bstride=K * Tn, B=B, D1=1, D2=Tn, O1=1, O2=Tn,
+    conv_call(x6=x6, wt=wt, M=M, Mpad=Mpad, K=K, Kpad=Kpad, ktab=kt, x=x.float().cuda(), x_bstride=K * Tn, B=B, D1=1, D2=Tn, O1=1, O2=Tn,
               S1=1, S2=1, plain=1, epi=EPI_LINEAR, flags=FLAG_SCALE | FLAG_RES, scale=pack_vec(g, Mpad), res=r.float().cuda(), bias=bias,
               y=y, y_bstride=M * Tn, y_cstride=Tn, tile_m=tile)
     assert maxerr(y, want) < 6e-5
 
 
 @pytest.mark.parametrize("freq", [True, False])
-def test_conv_transpose_4phase(lib, freq):
+def test_conv_transpose_4phase(lib, freq, x6):
     """ConvTranspose k=8 s=4 + crop + GELU + skip add (hdemucs.py:287,326-334) as a 4-phase GEMM."""
     if freq:
         B, C, Co, Fr, T = 2, 24, 12, 8, 40
@@ -159,21 +165,21 @@ def test_conv_transpose_4phase(lib, freq):
     if freq:
         kt = ktab(C, 2, 1, -1, 1, 0, 0, Fr * T, T, Kpad)
         y = torch.empty(B, Co, 4 * Fr, T, device="cuda")
-        conv_call(wt=wt, M=M, Mpad=Mpad, K=K, Kpad=Kpad, ktab=kt, x=x.float().cuda(), x_bstride=C * Fr * T, B=B, D1=Fr, D2=T,
+        conv_call(x6=x6, wt=wt, M=M, Mpad=Mpad, K=K, Kpad=Kpad, ktab=kt, x=x.float().cuda(), x_bstride=C * Fr * T, B=B, D1=Fr, D2=T,
                   O1=Fr + 1, O2=T, S1=1, S2=1, row_mode=1, epi=EPI_CONVTR, flags=FLAG_TR_FREQ | FLAG_GELU | FLAG_RES,
                   res=skip.float().cuda(), bias=bias, y=y, y_bstride=Co * 4 * Fr * T, y_cstride=4 * Fr * T, out_len=4 * Fr,
                   tile_m=tile)
     else:
         kt = ktab(C, 1, 2, 1, -1, 0, 0, L, L, Kpad)
         y = torch.empty(B, Co, Lout, device="cuda")
-        conv_call(wt=wt, M=M, Mpad=Mpad, K=K, Kpad=Kpad, ktab=kt, x=x.float().cuda(), x_bstride=C * L, B=B, D1=1, D2=L, O1=1,
+        conv_call(x6=x6, wt=wt, M=M, Mpad=Mpad, K=K, Kpad=Kpad, ktab=kt, x=x.float().cuda(), x_bstride=C * L, B=B, D1=1, D2=L, O1=1,
                   O2=L + 1, S1=1, S2=1, epi=EPI_CONVTR, flags=FLAG_GELU | FLAG_RES, res=skip.float().cuda(), bias=bias, y=y,
                   y_bstride=Co * Lout, y_cstride=Lout, out_len=Lout, tile_m=tile)
     assert maxerr(y, want) < 2e-5
 
 
 @pytest.mark.parametrize("freq", [True, False])
-def test_dconv_layer_three_passes(lib, freq):
+def test_dconv_layer_three_passes(lib, freq, x6):
     """One DConv residual layer (demucs.py:138-143,151-154): dilated conv3 + per-row statistics,
     in-place GroupNorm(1)+GELU pass, 1x1 with statistics-only pass, then GroupNorm + GLU + LayerScale +
     residual epilogue.  Frequency branch rows are (b, fr); time branch rows are b."""
@@ -206,7 +212,7 @@ def test_dconv_layer_three_passes(lib, freq):
     kt0 = ktab(C, 1, 3, 1, dil, 0, dil, P, D2, Kpad0)
     hid = torch.empty(B, h, P, device="cuda")
     stats = torch.zeros(nrows, SLOTS, 2, dtype=torch.float64, device="cuda")
-    conv_call(wt=wt0, M=M0, Mpad=Mpad0, K=K0, Kpad=Kpad0, ktab=kt0, x=xd, x_bstride=C * P, B=B, D1=D1, D2=D2, O1=D1, O2=D2, S1=1,
+    conv_call(x6=x6, wt=wt0, M=M0, Mpad=Mpad0, K=K0, Kpad=Kpad0, ktab=kt0, x=xd, x_bstride=C * P, B=B, D1=D1, D2=D2, O1=D1, O2=D2, S1=1,
               S2=1, row_mode=row_mode, epi=EPI_BIAS_STATS, bias=bias0, y=hid, y_bstride=h * P, y_cstride=P, stats=stats,
               tile_m=tile0)
     s = stats.sum(1).cpu()
@@ -227,7 +233,7 @@ def test_dconv_layer_three_passes(lib, freq):
     torch.cuda.synchronize()
     common = dict(wt=wt3, M=M3, Mpad=Mpad3, K=K3, Kpad=Kpad3, ktab=kt3, x=hid, x_bstride=h * P, B=B, D1=D1, D2=D2, O1=D1, O2=D2,
                   S1=1, S2=1, row_mode=row_mode, bias=bias3, tile_m=tile3, plain=1)
-    conv_call(epi=EPI_STATS_ONLY, stats=stats, **common)
+    conv_call(x6=x6, epi=EPI_STATS_ONLY, stats=stats, **common)
     s = stats.sum(1).cpu()
     cnt = 2 * C * (D2 if freq else P)
     mean2 = s[:, 0] / cnt
@@ -235,7 +241,7 @@ def test_dconv_layer_three_passes(lib, freq):
     st2 = torch.stack([mean2, 1.0 / torch.sqrt(var2 + 1e-5)], 1).float().cuda().contiguous()
     # pass 3: recompute, GroupNorm + GLU + LayerScale + residual
     out = torch.empty_like(xd)
-    conv_call(epi=EPI_GN_GLU, gn_stats=st2, gn_w=pack_vec(g2w, Mpad3, glu=True), gn_b=pack_vec(g2b, Mpad3, glu=True),
+    conv_call(x6=x6, epi=EPI_GN_GLU, gn_stats=st2, gn_w=pack_vec(g2w, Mpad3, glu=True), gn_b=pack_vec(g2b, Mpad3, glu=True),
               scale=ls.float().cuda(), res=xd, y=out, y_bstride=C * P, y_cstride=P, **common)
     assert maxerr(out, want) < 3e-5
 

@@ -45,6 +45,10 @@ def conv_case(name, M, Cin, K1, K2, D1, D2, pad1=0, pad2=0, glu=False, tile=0):
         setattr(d, f, v.data_ptr() if isinstance(v, torch.Tensor) else v)
     lib = _lib.load()
     st = C.c_void_p(_lib.current_stream_ptr())
+    if os.environ.get("BENCH_X6", "1") != "0" and tile_ in (64, 96, 128):
+        wx = torch.empty(6 * Kpad * Mpad, dtype=torch.uint8, device="cuda")
+        _lib.check(lib.mi_conv_pack_split(wt.data_ptr(), Kpad, Mpad, tile_, wx.data_ptr(), st), "pack")
+        d.wx = wx.data_ptr()
     ms = time_fn(lambda: _lib.check(lib.mi_conv_forward(C.byref(d), st), "conv"))
     flops = 2.0 * M * K * B * P
     print(f"{name:34s} M={M:5d} K={K:5d} N={B * P:7d} tile={tile_:3d}  {ms * 1e3:8.1f} us  {flops / ms / 1e9:7.1f} TFLOP/s", flush=True)
