@@ -10,7 +10,7 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdemucs_amd.so")
+LIB_PATH = os.environ.get("DEMUCS_AMD_LIB") or os.path.join(_HERE, "libdemucs_amd.so")   # override: kernel A/B builds
 
 MI_OK = 0
 

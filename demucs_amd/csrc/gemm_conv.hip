@@ -287,9 +287,6 @@ static int launch_tile(const mi_conv_desc &d, int tile, hipStream_t st) {
 int conv_pick_tile(int M) {
     if (M <= 32) return 32;
     if (M <= 64) return 64;
-    // both fit: prefer the tile whose M-tile count splits evenly over 4 or 8 XCD groups (gemm_x6.hip keeps one
-    // group's weight image L2 resident): M = 768 -> 8 x 96 rather than 6 x 128, M = 384 -> 4 x 96
-    if (M % 128 == 0 && M % 96 == 0 && (M / 128) % 4 != 0 && (M / 96) % 4 == 0) return 96;
     if (M % 128 == 0) return 128;
     if (M % 96 == 0) return 96;
     if (M <= 96) return 96;
@@ -323,7 +320,11 @@ int launch_conv(const mi_conv_desc &din, hipStream_t st) {
     const int64_t P = (int64_t)d.O1 * d.O2;
     const bool plain = d.plain && d.K == d.Kpad && P % 4 == 0 && d.x_bstride % 4 == 0 && ((uintptr_t)d.x & 15) == 0 &&
                        d.S1 == 1 && d.S2 == 1 && d.D1 == d.O1 && d.D2 == d.O2;
-    if (d.wx && conv_x6_supported(tile)) return launch_conv_x6(d, tile, plain, st);
+    static const int x6_mode = getenv("MI_X6_MODE") ? atoi(getenv("MI_X6_MODE")) : 0;   // bisecting: 1 plain only, 2 gather only
+    static const int x6_class = getenv("MI_X6_CLASS") ? atoi(getenv("MI_X6_CLASS")) : -1;   // bisecting: one kernel class only
+    if (x6_class >= 0 && x6_class != d.epi * 8 + (tile == 32 ? 0 : tile == 64 ? 1 : tile == 96 ? 2 : 3) * 2 + (plain ? 1 : 0)) d.wx = nullptr;
+    if (d.wx && conv_x6_supported(tile) && x6_mode == 3) return launch_conv_x6(d, tile, false, st);      // 3: table loader for all
+    if (d.wx && conv_x6_supported(tile) && (x6_mode == 0 || (x6_mode == 1) == plain)) return launch_conv_x6(d, tile, plain, st);
 #define MI_DISPATCH(E)                                              \
     case E: return plain ? launch_tile<E, 0, true>(d, tile, st) : launch_tile<E, 0, false>(d, tile, st)
 #define MI_LINEAR(F)                                                \

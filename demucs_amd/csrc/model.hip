@@ -79,7 +79,8 @@ static const char *kEpiNames[6] = {"linear", "glu", "bias_stats", "stats_only", 
 // class id of a conv launch: epilogue x tile x prologue
 static int conv_class(const mi_conv_desc &d, int tile) {
     const int ti = tile == 32 ? 0 : tile == 64 ? 1 : tile == 96 ? 2 : 3;
-    return d.epi * 8 + ti * 2 + (d.plain ? 1 : 0);
+    const bool x6 = d.wx && conv_x6_supported(tile);                 // split-bf16 main loop (gemm_x6.hip): own classes
+    return (x6 ? 48 : 0) + d.epi * 8 + ti * 2 + (d.plain ? 1 : 0);
 }
 
 int Model::conv(const mi_conv_desc &d, hipStream_t st) {
@@ -101,7 +102,8 @@ int Model::conv(const mi_conv_desc &d, hipStream_t st) {
     MI_HIP(hipEventRecord(p.b, st));
     prof.pending.push_back(p);
     ProfRow &row = prof.rows[cls];
-    if (!row.name[0]) snprintf(row.name, sizeof(row.name), "conv_gemm<%s,tile%d%s>", kEpiNames[d.epi], tile, d.plain ? ",1x1" : "");
+    if (!row.name[0])
+        snprintf(row.name, sizeof(row.name), "conv_gemm%s<%s,tile%d%s>", cls >= 48 ? "_x6" : "", kEpiNames[d.epi], tile, d.plain ? ",1x1" : "");
     return r;
 }
 
@@ -164,11 +166,14 @@ static std::vector<mi_ktab_entry> build_ktab(const Gather &g, int Kpad) {
     return tab;
 }
 
-// Second copy of the packed weights as exact 3-term bf16 tile images: selects the 6-product bf16 MFMA main loop.
-// MI_FP32_MFMA=1 keeps every layer on the native fp32 MFMA kernels (A/B comparisons, bisecting).
+// Second copy of the packed weights as exact 3-term bf16 tile images: selects the 6-product bf16 MFMA main loop
+// (gemm_x6.hip).  Opt-in (MI_X6=1) this round: the kernels pass every single-process parity test and are ~1.4x faster
+// on the transformer's linear layers, but when several PROCESSES share one GPU their results are intermittently
+// corrupted (tests/test_gpu_distributed.py, tools/micro/det3.py; cause not found yet), so the engine stays on the
+// native fp32 MFMA kernels by default.
 int Model::pack_split(PackedConv *pc) {
-    static const bool fp32_only = getenv("MI_FP32_MFMA") != nullptr;
-    if (fp32_only || !conv_x6_supported(pc->tile)) return MI_OK;
+    static const bool x6 = getenv("MI_X6") != nullptr && atoi(getenv("MI_X6")) != 0;
+    if (!x6 || !conv_x6_supported(pc->tile)) return MI_OK;
     MI_TRY(dev_alloc(&pc->wx, (size_t)6 * pc->Kpad * pc->Mpad));
     MI_TRY(launch_pack_split(pc->wt, pc->Kpad, pc->Mpad, pc->tile, pc->wx, nullptr));
     MI_HIP(hipStreamSynchronize(nullptr));

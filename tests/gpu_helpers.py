@@ -15,7 +15,6 @@ SLOTS = 32
 def pick_tile(M):
     if M <= 32: return 32
     if M <= 64: return 64
-    if M % 128 == 0 and M % 96 == 0 and (M // 128) % 4 != 0 and (M // 96) % 4 == 0: return 96
     if M % 128 == 0: return 128
     if M % 96 == 0: return 96
     if M <= 96: return 96

@@ -37,10 +37,11 @@ def _worker(rank, world, port, length, out_path):
     got = apply_model_sharded(m, mix, overlap=0.25)
     want = P.apply_model(m, mix, shifts=0, split=True, overlap=0.25)
     ok = bool(torch.equal(got, want)) and got.device.type == "cuda"
-    flags = [None] * world
+    flags, diffs = [None] * world, [None] * world
     dist.all_gather_object(flags, ok)
+    dist.all_gather_object(diffs, float((got - want).abs().max()))
     if rank == 0:
-        torch.save(dict(ok=all(flags), shape=tuple(got.shape)), out_path)
+        torch.save(dict(ok=all(flags), shape=tuple(got.shape), max_abs_diff=max(diffs)), out_path)
     dist.destroy_process_group()
 
 
@@ -49,4 +50,4 @@ def test_sharded_engine_equals_single_process(tmp_path, world, length):
     out_path = str(tmp_path / "res.pt")
     mp.spawn(_worker, args=(world, _free_port(), length, out_path), nprocs=world, join=True)
     res = torch.load(out_path)
-    assert res["ok"] and res["shape"] == (1, 4, 2, length)
+    assert res["ok"] and res["shape"] == (1, 4, 2, length), f"sharded != single process, max |diff| = {res['max_abs_diff']:.3e}"

@@ -1,0 +1,28 @@
+"""3 processes share the GPU; each repeats the same forward and reports which taps differ from its first run."""
+import sys, torch, torch.multiprocessing as mp
+sys.path.insert(0, ".")
+TAPS = ["x0", "xt0", "enc0", "enc1", "enc2", "enc3", "tenc0", "tenc1", "tenc2", "tenc3", "tr_f", "tr_t", "yspec", "ytime"]
+
+def worker(rank):
+    from demucs_amd.htdemucs import HTDemucs
+    from demucs_amd.weights import HTDemucsConfig, synthetic_state_dict
+    from demucs_amd.synth import synth_mix
+    cfg = HTDemucsConfig()
+    m = HTDemucs(cfg.sources, max_batch=2)
+    m.load_state_dict(synthetic_state_dict(cfg, 4)); m.to("cuda")
+    x = torch.stack([torch.from_numpy(synth_mix(50 + i, 343980, "tones")) for i in range(2)]).cuda()
+    ref, reft = None, None
+    for it in range(8):
+        y = m.forward_segments(x).clone()
+        taps = {t: m.tap(t, 2).clone() for t in TAPS}
+        torch.cuda.synchronize()
+        if ref is None:
+            ref, reft = y, taps
+            continue
+        if not torch.equal(y, ref):
+            bad = [(t, float((taps[t] - reft[t]).abs().max())) for t in TAPS if not torch.equal(taps[t], reft[t])]
+            print(f"rank {rank} iter {it}: out diff {float((y - ref).abs().max()):.3e}; taps: {bad}", flush=True)
+    print(f"rank {rank} done", flush=True)
+
+if __name__ == "__main__":
+    mp.spawn(worker, nprocs=int(sys.argv[1]) if len(sys.argv) > 1 else 3, join=True)
