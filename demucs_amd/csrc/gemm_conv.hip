@@ -13,7 +13,7 @@ namespace mi {
 // LFLAGS: the MI_FLAG_GELU/SCALE/RES bits of a LINEAR epilogue as compile-time constants (runtime flag branches
 // inside the unrolled epilogue made hipcc copy all 64 accumulators to VGPRs at once: 204 registers, 2 waves/SIMD)
 template <int WM, int WN, int TM, int TN, int EPI, int LFLAGS, bool PLAIN>
-__global__ __launch_bounds__(256, (TM * TN == 4 ? 3 : 4)) void conv_gemm_kernel(const mi_conv_desc d, const int N, const int MT) {
+__global__ __launch_bounds__(256, (TM * TN == 4 ? 3 : 4)) void conv_gemm_kernel(const mi_conv_desc d, const int N, const int MT, const int Gm) {
     constexpr int BM = WM * TM * 32;
     static_assert(WN * TN * 32 == BN, "block N tile is 128");
     static_assert(WM * WN == 4, "4 waves");
@@ -24,22 +24,8 @@ __global__ __launch_bounds__(256, (TM * TN == 4 ? 3 : 4)) void conv_gemm_kernel(
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
-    // XCD-aware tile order.  Workgroups are dealt round-robin over the 8 XCDs (private L2 each), so the MT
-    // workgroups that share one activation tile (same nt) are given ids that are equal mod 8: they run on ONE
-    // XCD and the tile is fetched into one L2 instead of eight.  Groups of 8 consecutive ids = 8 different nt.
     int mt, nt;
-    {
-        const int NT = gridDim.x / MT, full = (NT / 8) * 8;
-        const int id = blockIdx.x, per8 = 8 * MT;
-        if (id < full * MT) {
-            const int g = id / per8, r = id - g * per8;
-            nt = g * 8 + (r & 7);
-            mt = r >> 3;
-        } else {                                   // tail: fewer than 8 column tiles left
-            const int r = id - full * MT;
-            mt = r % MT; nt = full + r / MT;
-        }
-    }
+    if (!tile_of_block(MT, Gm, N, mt, nt)) return;      // grid padding (whole workgroup, before any barrier)
     const int m0 = mt * BM, n0 = nt * BN;
     const int P = d.O1 * d.O2;
 
@@ -164,7 +150,7 @@ typedef __attribute__((address_space(1))) const void gvoid_t;
 typedef __attribute__((address_space(3))) void lvoid_t;
 
 template <int EPI, int LFLAGS>
-__global__ __launch_bounds__(256, 3) void conv_gemm_dma_kernel(const mi_conv_desc d, const int N, const int MT) {
+__global__ __launch_bounds__(256, 3) void conv_gemm_dma_kernel(const mi_conv_desc d, const int N, const int MT, const int Gm) {
     constexpr int TM = 2, TN = 2, WN = 2, BM = 128;
     constexpr int SS = BK * (BM + BN);                       // floats per stage: A image then B image
     __shared__ __attribute__((aligned(16))) float smem[3 * SS];
@@ -172,12 +158,7 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_dma_kernel(const mi_conv_des
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     int mt, nt;
-    {
-        const int NT = gridDim.x / MT, full = (NT / 8) * 8;
-        const int id = blockIdx.x, per8 = 8 * MT;
-        if (id < full * MT) { const int g = id / per8, r = id - g * per8; nt = g * 8 + (r & 7); mt = r >> 3; }
-        else { const int r = id - full * MT; mt = r % MT; nt = full + r / MT; }
-    }
+    if (!tile_of_block(MT, Gm, N, mt, nt)) return;
     const int m0 = mt * BM, n0 = nt * BN;
     const int P = d.O1 * d.O2;
     const int o2v = d.o2_valid ? d.o2_valid : d.O2;
@@ -260,15 +241,21 @@ static int launch_cfg(const mi_conv_desc &d, hipStream_t st) {
     MI_REQUIRE(N64 < (1ll << 31) - 256, "conv: too many output positions (%lld)", (long long)N64);
     MI_REQUIRE(d.Mpad % BM == 0, "conv: Mpad %d not a multiple of the %d-row tile", d.Mpad, BM);
     const int N = (int)N64, MT = d.Mpad / BM, NT = ceil_div(N, BN);
+    // M groups (gemm_tile.h) halve this kernel's L2 misses on the 4 MiB weight matrices (TCC hit rate 48 % -> 74 %) but
+    // the misses were Infinity-Cache hits: no time is gained and every activation tile is then fetched from HBM by
+    // several XCDs (+10 % HBM bytes), so the fp32 path keeps one group unless MI_MGROUPS=1.
+    static const bool groups = getenv("MI_MGROUPS") != nullptr;
+    const int Gm = groups ? pick_m_groups(MT, (size_t)d.Kpad * d.Mpad * 4) : 1;
+    const unsigned grid = grouped_grid(MT, NT, Gm);
     if constexpr (PLAIN && BM == 128 && EPI == MI_EPI_LINEAR) {
         static const bool use_dma = getenv("MI_NO_DMA") == nullptr;
         if (use_dma) {
-            hipLaunchKernelGGL((conv_gemm_dma_kernel<EPI, LFLAGS>), dim3((unsigned)MT * NT), dim3(256), 0, st, d, N, MT);
+            hipLaunchKernelGGL((conv_gemm_dma_kernel<EPI, LFLAGS>), dim3(grid), dim3(256), 0, st, d, N, MT, Gm);
             MI_CHECK_LAUNCH();
             return MI_OK;
         }
     }
-    hipLaunchKernelGGL((conv_gemm_kernel<WM, WN, TM, TN, EPI, LFLAGS, PLAIN>), dim3((unsigned)MT * NT), dim3(256), 0, st, d, N, MT);
+    hipLaunchKernelGGL((conv_gemm_kernel<WM, WN, TM, TN, EPI, LFLAGS, PLAIN>), dim3(grid), dim3(256), 0, st, d, N, MT, Gm);
     MI_CHECK_LAUNCH();
     return MI_OK;
 }

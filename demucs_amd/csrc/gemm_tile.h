@@ -179,4 +179,24 @@ __device__ __forceinline__ void conv_epilogue(const mi_conv_desc &d, f32x16 (&ac
     }
 }
 
+// Tile order for the 8 per-XCD L2s (workgroups id, id + 8, ... share one): XCD x = id & 7 belongs to M group x % Gm
+// and N group x / Gm and only ever touches the weights of ITS M tiles (MT / Gm of them: sized by the host to stay L2
+// resident), while consecutive workgroups of an XCD walk those M tiles for one N tile (shared activation tile).
+// With Gm = 1 every XCD streams the whole weight matrix once per N tile; when that exceeds the 4 MiB L2, half of
+// all L2 requests miss (TCC_HIT / TCC_MISS, profiles/).  Returns false for the grid's padding workgroups.
+__device__ __forceinline__ bool tile_of_block(int MT, int Gm, int N, int &mt, int &nt) {
+    const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int MTx = MT / Gm, mi = j % MTx, ni = j / MTx;
+    mt = x % Gm + Gm * mi;
+    nt = x / Gm + (8 / Gm) * ni;
+    return nt * BN < N;
+}
+// host side: fewest M groups (1, 2, 4, 8; dividing MT) that bring one group's weights under 1.5 MiB, and the grid
+static inline int pick_m_groups(int MT, size_t weight_bytes) {
+    int Gm = 1;
+    while (Gm < 8 && MT % (2 * Gm) == 0 && weight_bytes / Gm > ((size_t)3 << 19)) Gm *= 2;
+    return Gm;
+}
+static inline unsigned grouped_grid(int MT, int NT, int Gm) { return 8u * (MT / Gm) * ((NT + 8 / Gm - 1) / (8 / Gm)); }
+
 }  // namespace mi

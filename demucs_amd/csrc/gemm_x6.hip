@@ -77,18 +77,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_x6_kernel(const mi_conv_desc
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
-    // Tile order for the 8 per-XCD L2s (blocks id, id + 8, ... share one): XCD x = id & 7 belongs to M group x % Gm and
-    // N group x / Gm and only ever touches the weight images of ITS M tiles (MT / Gm of them: sized by the host to
-    // stay L2 resident), while consecutive blocks of an XCD walk those M tiles for one N tile (shared activations).
-    // Without the M split every XCD streams the whole weight image once per N tile and half of all L2 requests miss.
     int mt, nt;
-    {
-        const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
-        const int MTx = MT / Gm, mi = j % MTx, ni = j / MTx;
-        mt = x % Gm + Gm * mi;
-        nt = x / Gm + (8 / Gm) * ni;
-        if (nt * BN >= N) return;                            // grid padding (whole block, before any barrier)
-    }
+    if (!tile_of_block(MT, Gm, N, mt, nt)) return;      // grid padding (whole workgroup, before any barrier)
     const int m0 = mt * BM, n0 = nt * BN;
     const int P = d.O1 * d.O2;
     const int o2v = d.o2_valid ? d.o2_valid : d.O2;
@@ -248,12 +238,8 @@ static int launch_cfg_x6(const mi_conv_desc &d, hipStream_t st) {
     MI_REQUIRE(N64 < (1ll << 31) - 256, "conv: too many output positions (%lld)", (long long)N64);
     MI_REQUIRE(d.Mpad % BM == 0, "conv: Mpad %d not a multiple of the %d-row tile", d.Mpad, BM);
     const int N = (int)N64, MT = d.Mpad / BM, NT = ceil_div(N, BN);
-    // M groups: the fewest (1, 2, 4, 8; dividing MT) that bring one group's weight image under kL2Share
-    constexpr size_t kL2Share = 3u << 19;                    // 1.5 MiB of the 4 MiB per-XCD L2
-    const size_t a_total = (size_t)d.Kpad * d.Mpad * 6;
-    int Gm = 1;
-    while (Gm < 8 && MT % (2 * Gm) == 0 && a_total / Gm > kL2Share) Gm *= 2;
-    const unsigned grid = 8u * (MT / Gm) * ceil_div(NT, 8 / Gm);
+    const int Gm = pick_m_groups(MT, (size_t)d.Kpad * d.Mpad * 6);
+    const unsigned grid = grouped_grid(MT, NT, Gm);
     hipLaunchKernelGGL((conv_gemm_x6_kernel<WM, WN, TM, TN, EPI, LFLAGS, PLAIN>), dim3(grid), dim3(256), 0, st, d, N, MT, Gm);
     MI_CHECK_LAUNCH();
     return MI_OK;

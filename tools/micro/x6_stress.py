@@ -5,10 +5,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 def worker(rank, plain, iters, x6):
+    mix = os.environ.get("MIX")                      # e.g. "11,10,01": per-rank (plain, x6) -> different kernels share the GPU
+    if mix:
+        plain, x6 = int(mix.split(",")[rank][0]), int(mix.split(",")[rank][1])
     from demucs_amd import _lib
     from gpu_helpers import EPI_LINEAR, ktab, pack_w
     torch.manual_seed(rank)
-    B, M, K, T = 8, int(os.environ.get("SM", 2048)), int(os.environ.get("SK", 512)), int(os.environ.get("ST", 2688))
+    B, M, K, T = int(os.environ.get("SB", 8)), int(os.environ.get("SM", 2048)), int(os.environ.get("SK", 512)), int(os.environ.get("ST", 2688))
     W = torch.randn(M, K) * 0.05
     wt, bias, M_, Mpad, K_, Kpad, tile = pack_w(W, torch.randn(M))
     kt = ktab(K, 1, 1, 1, 1, 0, 0, T, T, Kpad)
@@ -41,7 +44,8 @@ def worker(rank, plain, iters, x6):
                 continue
         else:
             y.zero_()
-            _lib.check(lib.mi_conv_forward(C.byref(d), st), "conv")
+            for _ in range(int(os.environ.get("BURST", "1"))):      # back-to-back launches without a host sync
+                _lib.check(lib.mi_conv_forward(C.byref(d), st), "conv")
             torch.cuda.synchronize()
             if ref is None:
                 ref = y.clone()

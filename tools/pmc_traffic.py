@@ -25,6 +25,13 @@ def klass(name):
     if m:
         wm, wn, tm, tn, epi, _, plain = m.groups()
         return f"conv_gemm<{EPI[int(epi)]},tile{TILE[(int(wm), int(wn), int(tm), int(tn))]}{',1x1' if plain == 'true' else ''}>"
+    m = re.search(r"conv_gemm_dma_kernel<(\d+), (\d+)>", name)      # LDS-DMA main loop of the plain 128-row LINEAR tile
+    if m:
+        return f"conv_gemm<{EPI[int(m.group(1))]},tile128,1x1>"
+    m = re.search(r"conv_gemm_x6_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (true|false)>", name)
+    if m:
+        wm, wn, tm, tn, epi, _, plain = m.groups()
+        return f"conv_gemm_x6<{EPI[int(epi)]},tile{TILE[(int(wm), int(wn), int(tm), int(tn))]}{',1x1' if plain == 'true' else ''}>"
     for k in ("attention_kernel", "dconv_row_kernel"):
         if k in name:
             return k
