@@ -6,6 +6,8 @@
 // (lane l: row/col l&31, k = l>>5) is one conflict-free ds_read_b32 per operand.
 // Arithmetic is exact fp32 (v_mfma_f32_32x32x2_f32 == k-ordered fmaf chain): the <=1e-4 parity
 // target against the fp32 CPU reference leaves no room for bf16 operands.
+#include <vector>
+
 #include "gemm_tile.h"
 
 namespace mi {
@@ -291,6 +293,83 @@ static float *conv_sink() {
     return p;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// MI_X6_VERIFY=1 (debugging aid for the split-bf16 path): every x6 launch is followed, on the same stream and with no
+// host synchronisation, by the fp32 kernel of the same layer into a scratch copy of the output and a comparison whose
+// verdict goes to a device-side log; the log is printed when the process exits.
+struct X6VerifyRec { unsigned bad, maxdiff_bits; int bmin, bmax, mmin, mmax, pmin, pmax; };
+struct X6VerifyInfo { int M, K, N, epi, flags, tile, plain, B, O1, O2, o2v; long long ybs, ycs; };
+static X6VerifyRec *g_vlog = nullptr;
+static std::vector<X6VerifyInfo> g_vinfo;
+static float *g_vscratch = nullptr;
+static size_t g_vscratch_elems = 0;
+constexpr int kVerifyMax = 1 << 16;
+
+__global__ void x6_verify_kernel(const float *__restrict__ a, const float *__restrict__ b, long long n, long long ybs, long long ycs,
+                                 X6VerifyRec *rec) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float x = a[i], y = b[i];
+        const float dlt = fabsf(x - y);
+        if (dlt > 1e-3f * (1.f + fabsf(y)) || (x != x) != (y != y)) {
+            atomicAdd(&rec->bad, 1u);
+            atomicMax(&rec->maxdiff_bits, __float_as_uint(dlt == dlt ? dlt : 3.0e38f));
+            const int bb = (int)(i / ybs), m = (int)((i % ybs) / ycs), p = (int)(i % ycs);
+            atomicMin(&rec->bmin, bb); atomicMax(&rec->bmax, bb);
+            atomicMin(&rec->mmin, m); atomicMax(&rec->mmax, m);
+            atomicMin(&rec->pmin, p); atomicMax(&rec->pmax, p);
+        }
+    }
+}
+
+static void x6_verify_dump() {
+    if (!g_vlog || g_vinfo.empty()) return;
+    (void)hipDeviceSynchronize();
+    std::vector<X6VerifyRec> h(g_vinfo.size());
+    if (hipMemcpy(h.data(), g_vlog, h.size() * sizeof(X6VerifyRec), hipMemcpyDeviceToHost) != hipSuccess) return;
+    size_t nbad = 0;
+    for (size_t i = 0; i < h.size(); ++i) {
+        if (!h[i].bad) continue;
+        const X6VerifyInfo &f = g_vinfo[i];
+        if (++nbad <= 40)
+            fprintf(stderr, "[x6 verify] launch %zu: M %d K %d N %d epi %d flags %d tile %d plain %d B %d O1 %d O2 %d o2v %d | %u bad, max %.3e, "
+                    "b %d-%d  m %d-%d  p %d-%d (col tiles %d-%d)\n", i, f.M, f.K, f.N, f.epi, f.flags, f.tile, f.plain, f.B, f.O1, f.O2, f.o2v,
+                    h[i].bad, __builtin_bit_cast(float, h[i].maxdiff_bits), h[i].bmin, h[i].bmax, h[i].mmin, h[i].mmax, h[i].pmin, h[i].pmax,
+                    h[i].pmin / BN, h[i].pmax / BN);
+    }
+    fprintf(stderr, "[x6 verify] %zu launches checked, %zu with mismatches\n", h.size(), nbad);
+}
+
+static int launch_conv_fp32_only(const mi_conv_desc &d, hipStream_t st);
+
+static int x6_verified_launch(const mi_conv_desc &d, int tile, bool plain, hipStream_t st) {
+    const bool checkable = d.epi != MI_EPI_STATS_ONLY && d.epi != MI_EPI_BIAS_STATS && d.res != d.y && (int)g_vinfo.size() < kVerifyMax;
+    if (!checkable) return launch_conv_x6(d, tile, plain, st);
+    if (!g_vlog) {
+        MI_HIP(hipMalloc((void **)&g_vlog, kVerifyMax * sizeof(X6VerifyRec)));
+        std::vector<X6VerifyRec> init(kVerifyMax, X6VerifyRec{0, 0, 1 << 30, -1, 1 << 30, -1, 1 << 30, -1});
+        MI_HIP(hipMemcpy(g_vlog, init.data(), init.size() * sizeof(X6VerifyRec), hipMemcpyHostToDevice));
+        atexit(x6_verify_dump);
+    }
+    const size_t elems = (size_t)d.B * (size_t)d.y_bstride;
+    if (elems > g_vscratch_elems) {
+        MI_HIP(hipStreamSynchronize(st));
+        if (g_vscratch) (void)hipFree(g_vscratch);
+        MI_HIP(hipMalloc((void **)&g_vscratch, elems * sizeof(float)));
+        g_vscratch_elems = elems;
+    }
+    MI_HIP(hipMemcpyAsync(g_vscratch, d.y, elems * sizeof(float), hipMemcpyDeviceToDevice, st));     // unwritten positions compare equal
+    MI_TRY(launch_conv_x6(d, tile, plain, st));
+    mi_conv_desc e = d;
+    e.wx = nullptr; e.y = g_vscratch;
+    MI_TRY(launch_conv_fp32_only(e, st));
+    const int id = (int)g_vinfo.size();
+    g_vinfo.push_back(X6VerifyInfo{d.M, d.K, d.B * d.O1 * d.O2, d.epi, d.flags, tile, plain ? 1 : 0, d.B, d.O1, d.O2, d.o2_valid, d.y_bstride, d.y_cstride});
+    hipLaunchKernelGGL(x6_verify_kernel, dim3(1024), dim3(256), 0, st, d.y, g_vscratch, (long long)elems, (long long)d.y_bstride, (long long)d.y_cstride, g_vlog + id);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+
 int launch_conv(const mi_conv_desc &din, hipStream_t st) {
     mi_conv_desc d = din;
     if (!d.sink) d.sink = conv_sink();
@@ -311,7 +390,9 @@ int launch_conv(const mi_conv_desc &din, hipStream_t st) {
     static const int x6_class = getenv("MI_X6_CLASS") ? atoi(getenv("MI_X6_CLASS")) : -1;   // bisecting: one kernel class only
     if (x6_class >= 0 && x6_class != d.epi * 8 + (tile == 32 ? 0 : tile == 64 ? 1 : tile == 96 ? 2 : 3) * 2 + (plain ? 1 : 0)) d.wx = nullptr;
     if (d.wx && conv_x6_supported(tile) && x6_mode == 3) return launch_conv_x6(d, tile, false, st);      // 3: table loader for all
-    if (d.wx && conv_x6_supported(tile) && (x6_mode == 0 || (x6_mode == 1) == plain)) return launch_conv_x6(d, tile, plain, st);
+    static const bool x6_verify = getenv("MI_X6_VERIFY") != nullptr;
+    if (d.wx && conv_x6_supported(tile) && (x6_mode == 0 || (x6_mode == 1) == plain))
+        return x6_verify ? x6_verified_launch(d, tile, plain, st) : launch_conv_x6(d, tile, plain, st);
 #define MI_DISPATCH(E)                                              \
     case E: return plain ? launch_tile<E, 0, true>(d, tile, st) : launch_tile<E, 0, false>(d, tile, st)
 #define MI_LINEAR(F)                                                \
@@ -337,6 +418,12 @@ int launch_conv(const mi_conv_desc &din, hipStream_t st) {
     }
 #undef MI_DISPATCH
     return set_error(MI_EINVAL, "conv: unsupported epilogue %d", d.epi);
+}
+
+static int launch_conv_fp32_only(const mi_conv_desc &d, hipStream_t st) {
+    mi_conv_desc e = d;
+    e.wx = nullptr;
+    return launch_conv(e, st);
 }
 
 }  // namespace mi

@@ -4,6 +4,14 @@ sys.path.insert(0, ".")
 TAPS = ["x0", "xt0", "enc0", "enc1", "enc2", "enc3", "tenc0", "tenc1", "tenc2", "tenc3", "tr_f", "tr_t", "yspec", "ytime"]
 
 def worker(rank):
+    import os
+    only = os.environ.get("X6_RANKS")                 # e.g. "0": only these ranks run the split-bf16 path, the others fp32
+    if only is not None:
+        if str(rank) in only.split(","):
+            os.environ["MI_X6"] = "1"
+        else:
+            os.environ.pop("MI_X6", None)
+        print(f"rank {rank}: MI_X6={os.environ.get('MI_X6')}", flush=True)
     from demucs_amd.htdemucs import HTDemucs
     from demucs_amd.weights import HTDemucsConfig, synthetic_state_dict
     from demucs_amd.synth import synth_mix
