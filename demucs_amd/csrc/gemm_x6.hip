@@ -62,6 +62,9 @@ int launch_pack_split(const float *wt, int Kpad, int Mpad, int tile_m, void *wx,
     return MI_OK;
 }
 
+#ifndef MI_X6_ABL
+#define MI_X6_ABL 0          /* victim-side bisect builds: 1 = one MFMA per K step instead of 24, 4 = no epilogue */
+#endif
 template <int WM, int WN, int TM, int TN, int EPI, int LFLAGS, bool PLAIN>
 __global__ __launch_bounds__(256, 2) void conv_gemm_x6_kernel(const mi_conv_desc d, const int N, const int MT, const int Gm) {
     constexpr int BM = WM * TM * 32;
@@ -187,6 +190,16 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_x6_kernel(const mi_conv_desc
             for (int b = 0; b < TN; ++b)
                 bf[b][p] = *reinterpret_cast<const bf16x8 *>(Bs + (((p * 2 + lh) * BN) + (wn * TN + b) * 32 + li) * 16);
         }
+        if (MI_X6_ABL & 8) {                  // same instruction stream, all-zero operands (minimal switching power)
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+#pragma unroll
+                for (int a = 0; a < TM; ++a) { u32x4 z = {0u, 0u, 0u, 0u}; asm volatile("" : "+v"(z)); af[a][p] = __builtin_bit_cast(bf16x8, z); }
+#pragma unroll
+                for (int b = 0; b < TN; ++b) { u32x4 z = {0u, 0u, 0u, 0u}; asm volatile("" : "+v"(z)); bf[b][p] = __builtin_bit_cast(bf16x8, z); }
+            }
+        }
         __builtin_amdgcn_sched_barrier(0);
         if (kt + 1 < nk) {
             MI_A_DMA(kt + 1, cur ^ 1);
@@ -208,7 +221,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_x6_kernel(const mi_conv_desc
             for (int a = 0; a < TM; ++a)
 #pragma unroll
                 for (int b = 0; b < TN; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][PA[q]], bf[b][PB[q]], acc[a][b], 0, 0, 0);
+                    if (!(MI_X6_ABL & 1) || (q == 0 && a == 0 && b == 0))
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][PA[q]], bf[b][PB[q]], acc[a][b], 0, 0, 0);
         if (PLAIN || kt + 1 < nk) MI_B_STORE(cur ^ 1);
         if constexpr (PLAIN) {
             // the split of the next activation tile (~70 VALU) issues in the shadow of this step's MFMAs
@@ -228,6 +242,12 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_x6_kernel(const mi_conv_desc
 #undef MI_BRAW_READ
 #undef MI_B_STORE
 
+    if (MI_X6_ABL & 4) {                     // no epilogue: one store per thread keeps the loop alive
+        float s = 0.f;
+        for (int a = 0; a < TM; ++a) for (int b = 0; b < TN; ++b) for (int r = 0; r < 16; ++r) s += acc[a][b][r];
+        d.sink[threadIdx.x] = s;
+        return;
+    }
     conv_epilogue<TM, TN, EPI, LFLAGS>(d, acc, m0, n0, wm, wn, N, P, o2v);
 }
 

@@ -4,7 +4,7 @@ sys.path.insert(0, ".")
 TAPS = ["x0", "xt0", "enc0", "enc1", "enc2", "enc3", "tenc0", "tenc1", "tenc2", "tenc3", "tr_f", "tr_t", "yspec", "ytime"]
 
 def worker(rank):
-    import os
+    import os, torch
     only = os.environ.get("X6_RANKS")                 # e.g. "0": only these ranks run the split-bf16 path, the others fp32
     if only is not None:
         if str(rank) in only.split(","):
@@ -12,6 +12,17 @@ def worker(rank):
         else:
             os.environ.pop("MI_X6", None)
         print(f"rank {rank}: MI_X6={os.environ.get('MI_X6')}", flush=True)
+    if str(rank) in os.environ.get("BF16_RANKS", "").split(","):
+        # neighbour load that never touches this package: dense bf16 GEMMs from the vendor BLAS (same bf16 MFMA instructions)
+        import time
+        a = torch.randn(8192, 8192, device="cuda", dtype=torch.bfloat16); b = torch.randn(8192, 8192, device="cuda", dtype=torch.bfloat16)
+        t0 = time.time()
+        while time.time() - t0 < float(os.environ.get("BF16_SECONDS", "12")):
+            for _ in range(20):
+                c = a @ b
+            torch.cuda.synchronize()
+        print(f"rank {rank}: bf16 matmul load done", flush=True)
+        return
     from demucs_amd.htdemucs import HTDemucs
     from demucs_amd.weights import HTDemucsConfig, synthetic_state_dict
     from demucs_amd.synth import synth_mix
