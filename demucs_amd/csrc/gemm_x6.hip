@@ -63,7 +63,8 @@ int launch_pack_split(const float *wt, int Kpad, int Mpad, int tile_m, void *wx,
 }
 
 #ifndef MI_X6_ABL
-#define MI_X6_ABL 0          /* victim-side bisect builds: 1 = one MFMA per K step instead of 24, 4 = no epilogue */
+#define MI_X6_ABL 0          /* victim-side bisect builds: 1 = one MFMA per K step instead of 24, 4 = no epilogue, 8 = zero operands,
+                                16 = 32 idle cycles after every MFMA, 32 = 64 idle cycles after every 4 MFMAs */
 #endif
 template <int WM, int WN, int TM, int TN, int EPI, int LFLAGS, bool PLAIN>
 __global__ __launch_bounds__(256, 2) void conv_gemm_x6_kernel(const mi_conv_desc d, const int N, const int MT, const int Gm) {
@@ -175,12 +176,22 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_x6_kernel(const mi_conv_desc
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int cur = 0;
+    bf16x8 keepa[TM][3], keepb[TN][3];       // MI_X6_ABL & 128 only
     for (int kt = 0; kt < nk; ++kt) {
         // All fragment reads of this K step are ISSUED before the loads of the next one: hipcc orders every ds_read
         // behind pending LDS-DMA with s_waitcnt vmcnt(0) (it cannot tell the ring stages apart), which would
         // otherwise make each step wait for the loads it has just issued.
         const unsigned char *As = smem + cur * STAGE, *Bs = As + A_BYTES;
         bf16x8 af[TM][3], bf[TN][3];
+        if ((MI_X6_ABL & 128) && kt > 0) {   // fragments fetched in the first step only: 24 MFMAs per step, (almost) no ds_read_b128
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+#pragma unroll
+                for (int a = 0; a < TM; ++a) af[a][p] = keepa[a][p];
+#pragma unroll
+                for (int b = 0; b < TN; ++b) bf[b][p] = keepb[b][p];
+            }
+        } else
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
 #pragma unroll
@@ -189,6 +200,25 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_x6_kernel(const mi_conv_desc
 #pragma unroll
             for (int b = 0; b < TN; ++b)
                 bf[b][p] = *reinterpret_cast<const bf16x8 *>(Bs + (((p * 2 + lh) * BN) + (wn * TN + b) * 32 + li) * 16);
+        }
+        if (MI_X6_ABL & 128) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+#pragma unroll
+                for (int a = 0; a < TM; ++a) keepa[a][p] = af[a][p];
+#pragma unroll
+                for (int b = 0; b < TN; ++b) keepb[b][p] = bf[b][p];
+            }
+        }
+        if (MI_X6_ABL & 64) {                 // all fragment reads stay alive although only one MFMA consumes them
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+#pragma unroll
+                for (int a = 0; a < TM; ++a) { u32x4 z = __builtin_bit_cast(u32x4, af[a][p]); asm volatile("" : "+v"(z)); af[a][p] = __builtin_bit_cast(bf16x8, z); }
+#pragma unroll
+                for (int b = 0; b < TN; ++b) { u32x4 z = __builtin_bit_cast(u32x4, bf[b][p]); asm volatile("" : "+v"(z)); bf[b][p] = __builtin_bit_cast(bf16x8, z); }
+            }
         }
         if (MI_X6_ABL & 8) {                  // same instruction stream, all-zero operands (minimal switching power)
             typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -221,8 +251,11 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_x6_kernel(const mi_conv_desc
             for (int a = 0; a < TM; ++a)
 #pragma unroll
                 for (int b = 0; b < TN; ++b)
-                    if (!(MI_X6_ABL & 1) || (q == 0 && a == 0 && b == 0))
+                    if (!(MI_X6_ABL & 1) || (q == 0 && a == 0 && b == 0)) {
                         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][PA[q]], bf[b][PB[q]], acc[a][b], 0, 0, 0);
+                        if (MI_X6_ABL & 16) asm volatile("s_nop 15\n\ts_nop 15");                     // gap after every MFMA
+                        if ((MI_X6_ABL & 32) && a == TM - 1 && b == TN - 1) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15");   // gap after each group
+                    }
         if (PLAIN || kt + 1 < nk) MI_B_STORE(cur ^ 1);
         if constexpr (PLAIN) {
             // the split of the next activation tile (~70 VALU) issues in the shadow of this step's MFMAs
