@@ -23,6 +23,10 @@ def worker(rank):
             torch.cuda.synchronize()
         print(f"rank {rank}: bf16 matmul load done", flush=True)
         return
+    if rank == 0 and os.environ.get("CULPRIT"):
+        import subprocess                              # an external program as the neighbour, e.g. "tools/micro/mfma_neighbour 1 12"
+        print(subprocess.run(os.environ["CULPRIT"].split(), capture_output=True, text=True).stdout.strip(), flush=True)
+        return
     from demucs_amd.htdemucs import HTDemucs
     from demucs_amd.weights import HTDemucsConfig, synthetic_state_dict
     from demucs_amd.synth import synth_mix
