@@ -5,6 +5,10 @@ Tolerance: BASELINE.json's north_star states <= 1e-4 max-abs sample deviation fr
 reference; asserted below on the final output (scored against float64 truth), with the SDR of
 demucs/evaluate.py:30-43 reported alongside.
 """
+import os
+import subprocess
+import sys
+
 import numpy as np
 import pytest
 import torch
@@ -120,3 +124,17 @@ def test_model_rejects_cpu_and_bad_shapes():
         m(torch.zeros(1, 2, SL + 1, device="cuda"))   # htdemucs.py:521-524
     with pytest.raises(ValueError):
         m.forward_segments(torch.zeros(1, 3, SL, device="cuda"))
+
+
+@pytest.mark.skipif(os.environ.get("MI_X6") is not None, reason="already inside the split-bf16 re-run")
+def test_split_bf16_gemm_mode_keeps_parity():
+    """Opt-in mode MI_X6=1 (gemm_x6.hip: fp32 operands as three exact bf16 terms, six bf16 MFMA products, fp32 accumulate):
+    the reference-golden and float64-oracle parity tests above must hold unchanged with the transformer / 1x1 layers on that
+    path.  Re-runs them in a fresh process (the switch is read when the weights are packed); single process, as DESIGN.md
+    section 8 requires for this mode."""
+    env = dict(os.environ, MI_X6="1", MI_X6_MODE="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k",
+                        "reference_golden or float64_oracle", "-p", "no:cacheprovider"], env=env, capture_output=True, text=True,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "passed" in r.stdout
