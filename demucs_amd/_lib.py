@@ -67,6 +67,8 @@ SIGNATURES = {
     "mi_stft_cac": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "mi_istft_cac": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "mi_conv_forward": (C.c_int, [C.POINTER(MiConvDesc), C.c_void_p]),
+    "mi_resample_frac": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64,
+                                   C.c_void_p]),
     "mi_conv_pack_split": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "mi_attention": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_void_p]),

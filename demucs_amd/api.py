@@ -12,6 +12,7 @@ from typing import Callable, Dict, Optional, Tuple
 
 import torch
 
+from .audio import convert_audio
 from .apply import BagOfModels, apply_model
 
 __all__ = ["Separator", "LoadModelError"]
@@ -61,8 +62,7 @@ class Separator:
         """api.py:241-291.  `wav` (channels, length) float32 is normalised IN PLACE by the mono
         mean / std for the duration of the call and restored before returning."""
         if sr is not None and sr != self._samplerate:
-            raise NotImplementedError("resampling (demucs.audio.convert_audio / julius) is outside the accelerated path; "
-                                      f"resample to {self._samplerate} Hz first")
+            wav = convert_audio(wav, sr, self._samplerate, self._audio_channels, device=self._device)
         ref = wav.mean(0)
         wav -= ref.mean()
         wav /= ref.std() + 1e-8

@@ -195,6 +195,12 @@ int mi_conv_forward(const struct mi_conv_desc *desc, void *stream) {
     return launch_conv(*desc, (hipStream_t)stream);
 }
 
+int mi_resample_frac(const float *x_dev, int32_t rows, int64_t length, const float *table_dev, int32_t old_sr, int32_t new_sr,
+                     int32_t width, float *y_dev, int64_t out_length, void *stream) {
+    MI_REQUIRE(x_dev && table_dev && y_dev && old_sr > 0 && new_sr > 0 && width > 0, "mi_resample_frac: bad argument");
+    return launch_resample_frac(x_dev, rows, length, table_dev, old_sr, new_sr, width, y_dev, out_length, (hipStream_t)stream);
+}
+
 int mi_conv_pack_split(const float *wt_dev, int32_t Kpad, int32_t Mpad, int32_t tile_m, void *wx_dev, void *stream) {
     MI_REQUIRE(wt_dev && wx_dev && Kpad > 0 && Mpad > 0 && conv_x6_supported(tile_m), "mi_conv_pack_split: bad argument");
     return launch_pack_split(wt_dev, Kpad, Mpad, tile_m, wx_dev, (hipStream_t)stream);

@@ -73,4 +73,8 @@ int launch_ola_accumulate(float *acc, int64_t acc_len, int rows, const float *mo
 int launch_ola_finish(float *acc, int64_t acc_len, int rows, int64_t acc_off0, const int64_t *offs_dev, const int32_t *lens_dev,
                       int n_segments, int max_len, const float *weight, hipStream_t st);
 
+// resample.hip
+int launch_resample_frac(const float *x, int rows, int64_t L, const float *table, int old_sr, int new_sr, int width, float *y,
+                         int64_t Lout, hipStream_t st);
+
 }  // namespace mi

@@ -117,6 +117,13 @@ int mi_ola_accumulate(float *acc_dev, int64_t acc_len, int32_t rows, const float
 int mi_ola_finish(float *acc_dev, int64_t acc_len, int32_t rows, int64_t acc_off0, const int64_t *offs_idx_dev,
                   const int32_t *lens_idx_dev, int32_t n_segments, int32_t max_len, const float *weight_dev, void *stream);
 
+/* mi_resample_frac: `julius.resample_frac` as called by `demucs.audio.convert_audio` (demucs/audio.py:169-172), the step
+ *   `Separator.separate_tensor` runs first when the input sample rate differs from the model's (demucs/api.py:265-266).
+ *   old_sr / new_sr already divided by their gcd; table_dev (new_sr, 2*width + old_sr) is julius' windowed-sinc kernel bank
+ *   (built by demucs_amd/audio.py); x_dev (rows, length) -> y_dev (rows, out_length), out_length <= new_sr*(length/old_sr + 1). */
+int mi_resample_frac(const float *x_dev, int32_t rows, int64_t length, const float *table_dev, int32_t old_sr, int32_t new_sr,
+                     int32_t width, float *y_dev, int64_t out_length, void *stream);
+
 /* ---- kernel-level entry points (parity tests; same kernels the forward uses) --------------
  * mi_stft_cac: `_magnitude(_spec(mix))` (demucs/htdemucs.py:420-461, demucs/spec.py:11-27):
  *   mix_dev (B,2,L) -> cac_dev (B,4,2048,ceil(L/1024)), channel order [c0.re,c0.im,c1.re,c1.im]. */
