@@ -35,7 +35,7 @@ def worker(rank):
     m.load_state_dict(synthetic_state_dict(cfg, 4)); m.to("cuda")
     x = torch.stack([torch.from_numpy(synth_mix(50 + i, 343980, "tones")) for i in range(2)]).cuda()
     ref, reft = None, None
-    for it in range(8):
+    for it in range(int(os.environ.get("DET_ITERS", "8"))):
         y = m.forward_segments(x).clone()
         taps = {t: m.tap(t, 2).clone() for t in TAPS}
         torch.cuda.synchronize()
