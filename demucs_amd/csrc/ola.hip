@@ -27,12 +27,33 @@ __global__ __launch_bounds__(256) void ola_accumulate_kernel(float *__restrict__
                                                              int rows, int valid, const int64_t *__restrict__ offs,
                                                              const int32_t *__restrict__ lens, const int32_t *__restrict__ trim, int B,
                                                              int64_t span_lo, int64_t span_hi, const float *__restrict__ weight) {
-    const int64_t p = span_lo + (int64_t)blockIdx.x * 256 + threadIdx.x;
+    // the items that overlap this workgroup's 256 positions, in ascending item order (= the reference's summation
+    // order), found once per workgroup instead of B range checks per sample
+    __shared__ int n_hit;
+    __shared__ int hit[256];
+    const int64_t p0 = span_lo + (int64_t)blockIdx.x * 256;
+    if (threadIdx.x == 0) n_hit = 0;
+    __syncthreads();
+    for (int base = 0; base < B; base += 256) {           // B <= 256 in practice: one round
+        const int i = base + threadIdx.x;
+        const bool over = i < B && offs[i] < p0 + 256 && offs[i] + lens[i] > p0;
+        const unsigned long long m = __ballot(over);
+        // wave-ordered compaction keeps ascending item order: waves append in order through the barrier sequence below
+        for (int w = 0; w < 4; ++w) {
+            if ((threadIdx.x >> 6) == w && over) hit[n_hit + __popcll(m & ((1ull << (threadIdx.x & 63)) - 1))] = i;
+            __syncthreads();
+            if (threadIdx.x == w * 64) n_hit += __popcll(m);
+            __syncthreads();
+        }
+    }
+    const int64_t p = p0 + threadIdx.x;
     if (p >= span_hi || p >= acc_len) return;
     const int row = blockIdx.y;
     float a = acc[(size_t)row * acc_len + p];
     bool touched = false;
-    for (int i = 0; i < B; ++i) {
+    const int nh = n_hit;
+    for (int h = 0; h < nh; ++h) {
+        const int i = hit[h];
         const int64_t j = p - offs[i];
         if (j >= 0 && j < lens[i]) {
             const float v = mo[((size_t)i * rows + row) * valid + trim[i] + j];
@@ -48,12 +69,19 @@ __global__ __launch_bounds__(256) void ola_accumulate_kernel(float *__restrict__
 __global__ __launch_bounds__(256) void ola_finish_kernel(float *__restrict__ acc, int64_t acc_len, int64_t acc_off0,
                                                          const int64_t *__restrict__ offs, const int32_t *__restrict__ lens, int n,
                                                          int max_len, const float *__restrict__ weight) {
+    // one binary search per workgroup (first segment that can still cover the workgroup's first position)
+    __shared__ int lo_s;
+    if (threadIdx.x == 0) {
+        const int64_t pb = acc_off0 + (int64_t)blockIdx.x * 256;
+        int lo = 0, hi = n;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (offs[mid] > pb - max_len) hi = mid; else lo = mid + 1; }
+        lo_s = lo;
+    }
+    __syncthreads();
     const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (q >= acc_len) return;
     const int64_t p = acc_off0 + q;
-    // first segment with off > p - max_len
-    int lo = 0, hi = n;
-    while (lo < hi) { const int mid = (lo + hi) >> 1; if (offs[mid] > p - max_len) hi = mid; else lo = mid + 1; }
+    const int lo = lo_s;                                  // segments before lo end at or before pb <= p: they add nothing
     float sw = 0.f;
     for (int i = lo; i < n && offs[i] <= p; ++i) {
         const int64_t j = p - offs[i];
@@ -75,6 +103,7 @@ int launch_ola_accumulate(float *acc, int64_t acc_len, int rows, const float *mo
                           const int32_t *lens_dev, const int32_t *trim_dev, int B, int64_t span_lo, int64_t span_hi,
                           const float *weight, hipStream_t st) {
     MI_REQUIRE(span_hi > span_lo && span_lo >= 0, "ola: empty span");
+    MI_REQUIRE(B >= 1 && B <= 256, "ola: %d segments per call (at most 256)", B);
     hipLaunchKernelGGL(ola_accumulate_kernel, dim3(ceil_div(span_hi - span_lo, 256), rows), dim3(256), 0, st, acc, acc_len, model_out,
                        rows, valid, offs_dev, lens_dev, trim_dev, B, span_lo, span_hi, weight);
     MI_CHECK_LAUNCH();
