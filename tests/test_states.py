@@ -1,0 +1,112 @@
+"""Checkpoint-package reader (demucs/states.py:50-107 -> demucs_amd/states.py).  No released checkpoint is available
+offline: the packages are written here in the reference's format (serialize_model, states.py:138-157), with a stand-in
+module `demucs.htdemucs` so that the pickled class reference carries the reference's qualified name.  Parity unpinned."""
+import sys
+import types
+import warnings
+from fractions import Fraction
+
+import pytest
+import torch
+
+from demucs_amd import states
+from demucs_amd.htdemucs import HTDemucs
+from demucs_amd.weights import HTDemucsConfig, synthetic_state_dict
+
+
+@pytest.fixture()
+def fake_reference_modules(monkeypatch):
+    """`demucs.htdemucs.HTDemucs` / `demucs.hdemucs.HDemucs` as picklable names (what torch.save records for `klass`)."""
+    pkg = types.ModuleType("demucs")
+    made = {}
+    for mod, cls in (("htdemucs", "HTDemucs"), ("hdemucs", "HDemucs")):
+        m = types.ModuleType(f"demucs.{mod}")
+        c = type(cls, (), {"__module__": f"demucs.{mod}"})
+        setattr(m, cls, c)
+        setattr(pkg, mod, m)
+        monkeypatch.setitem(sys.modules, f"demucs.{mod}", m)
+        made[cls] = c
+    monkeypatch.setitem(sys.modules, "demucs", pkg)
+    return made
+
+
+def _package(klass, half):
+    cfg = HTDemucsConfig()
+    state = {k: torch.from_numpy(v).to(torch.half if half else torch.float32) for k, v in synthetic_state_dict(cfg, 7).items()}
+    return {"klass": klass, "args": (list(cfg.sources),), "kwargs": {"segment": Fraction(39, 5), "t_dropout": 0.0, "made_up_knob": 3},
+            "state": state, "training_args": {"lr": 3e-4}}
+
+
+@pytest.mark.parametrize("half", [False, True])
+def test_file_roundtrip_without_executing_the_file(tmp_path, fake_reference_modules, half):
+    path = tmp_path / "955717e8-8726e21a.th"
+    torch.save(_package(fake_reference_modules["HTDemucs"], half), path)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        model = states.load_model(path)
+    assert any("Dropping inexistant parameter made_up_knob" in str(x.message) for x in w)
+    assert isinstance(model, HTDemucs) and model.sources == HTDemucsConfig().sources and model.segment == Fraction(39, 5)
+    want = synthetic_state_dict(HTDemucsConfig(), 7)
+    got = model.state_dict()
+    assert set(got) == set(want)
+    k = "crosstransformer.layers.0.linear1.weight"
+    ref = torch.from_numpy(want[k])
+    ref = ref.half().float() if half else ref
+    assert torch.equal(torch.as_tensor(got[k]).float(), ref)
+
+
+def test_strict_rejects_unknown_keywords_and_dict_input_works(fake_reference_modules):
+    pkg = _package(fake_reference_modules["HTDemucs"], False)
+    with pytest.raises(ValueError):
+        states.load_model(dict(pkg), strict=True)
+    model = states.load_model({**pkg, "klass": "demucs.htdemucs.HTDemucs", "kwargs": {"segment": Fraction(39, 5)}}, strict=True)
+    assert isinstance(model, HTDemucs)
+
+
+def test_other_architectures_and_quantised_states_are_refused(tmp_path, fake_reference_modules):
+    path = tmp_path / "hd.th"
+    torch.save(_package(fake_reference_modules["HDemucs"], False), path)
+    with pytest.raises(ValueError, match="demucs.hdemucs.HDemucs"):
+        states.load_model(path)
+    pkg = _package(fake_reference_modules["HTDemucs"], False)
+    pkg["state"] = {"__quantized": True, "quantized": []}
+    with pytest.raises(ValueError, match="quantised"):
+        states.load_model(pkg)
+    with pytest.raises(ValueError):
+        states.load_model(12)
+
+
+def test_arbitrary_pickled_objects_are_not_deserialised(tmp_path):
+    class Evil:
+        def __reduce__(self):
+            return (print, ("executed from the checkpoint",))
+    path = tmp_path / "evil.th"
+    torch.save({"klass": Evil(), "args": (), "kwargs": {}, "state": {}}, path)
+    with pytest.raises(Exception):
+        states.read_package(path)
+
+
+def test_local_repo_reads_signatures_checksums_and_bags(tmp_path, fake_reference_modules):
+    import hashlib
+    from demucs_amd.apply import BagOfModels
+    sigs = ["f7e0c4bc", "d12395a8"]
+    for i, sig in enumerate(sigs):
+        tmp = tmp_path / f"{sig}.tmp"
+        torch.save(_package(fake_reference_modules["HTDemucs"], True), tmp)
+        digest = hashlib.sha256(tmp.read_bytes()).hexdigest()[:8]
+        tmp.rename(tmp_path / (f"{sig}-{digest}.th" if i == 0 else f"{sig}.th"))
+    (tmp_path / "two_ft.yaml").write_text("models: ['f7e0c4bc', 'd12395a8']\nweights: [[1., 0., 0., 0.], [0., 1., 1., 1.]]\n")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        repo = states.LocalRepo(tmp_path, max_batch=2)
+        assert repo.has_model("two_ft") and repo.has_model("d12395a8") and not repo.has_model("nope")
+        bag = repo.get_model("two_ft")
+        assert isinstance(bag, BagOfModels) and len(bag.models) == 2 and bag.weights[1] == [0.0, 1.0, 1.0, 1.0]
+        assert isinstance(repo.get_model("f7e0c4bc"), HTDemucs)
+    with pytest.raises(states.ModelLoadingError):
+        repo.get_model("nope")
+    # a corrupted file no longer matches the checksum in its name
+    bad = next(p for p in tmp_path.iterdir() if p.name.startswith("f7e0c4bc-"))
+    bad.write_bytes(bad.read_bytes()[:-1] + b"\\0")
+    with pytest.raises(states.ModelLoadingError, match="Invalid checksum"):
+        states.LocalRepo(tmp_path).get_model("f7e0c4bc")
