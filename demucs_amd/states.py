@@ -93,18 +93,13 @@ class ModelLoadingError(RuntimeError):
 
 
 def check_checksum(path: Path, checksum: str):
-    """demucs/repo.py:30-39: the file name's suffix is the first len(checksum) hex digits of the file's sha256."""
+    """demucs/repo.py:29-40: the suffix in the file name is the leading hex digits of the file's sha256."""
     import hashlib
-    sha = hashlib.sha256()
     with open(path, "rb") as file:
-        while True:
-            buf = file.read(2 ** 20)
-            if not buf:
-                break
-            sha.update(buf)
-    actual = sha.hexdigest()[:len(checksum)]
-    if actual != checksum:
-        raise ModelLoadingError(f"Invalid checksum for file {path}, expected {checksum} but got {actual}")
+        digest = hashlib.file_digest(file, "sha256").hexdigest() if hasattr(hashlib, "file_digest") else \
+            hashlib.sha256(file.read()).hexdigest()
+    if not digest.startswith(checksum):
+        raise ModelLoadingError(f"Invalid checksum for file {path}, expected {checksum} but got {digest[:len(checksum)]}")
 
 
 class LocalRepo:
