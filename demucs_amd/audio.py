@@ -80,3 +80,39 @@ def convert_audio(wav: torch.Tensor, from_samplerate: int, to_samplerate: int, c
     """demucs/audio.py:169-172."""
     wav = convert_audio_channels(wav, channels)
     return resample_frac(wav, from_samplerate, to_samplerate, device)
+
+
+# ---- after the separation: what demucs.separate does with the stems before any encoder sees them ----------------------
+def prevent_clip(wav: torch.Tensor, mode="rescale") -> torch.Tensor:
+    """demucs/audio.py:218-234, on whatever device the stems live (they stay in HBM with split=True on the engine)."""
+    if mode is None or mode == "none":
+        return wav
+    assert wav.dtype.is_floating_point, "too late for clipping"
+    if mode == "rescale":
+        return wav / max(1.01 * wav.abs().max(), 1)
+    if mode == "clamp":
+        return wav.clamp(-0.99, 0.99)
+    if mode == "tanh":
+        return torch.tanh(wav)
+    raise ValueError(f"Invalid mode {mode}")
+
+
+def two_stems(origin: torch.Tensor, stems: dict, stem: str, other_method: str = "add") -> dict:
+    """`--two-stems STEM` of demucs/separate.py:189-218 as a tensor function: returns {STEM: ..., "no_STEM": sum of the
+    other stems} for other_method="add", {STEM: ..., "minus_STEM": origin - STEM} for "minus", {STEM: ...} for "none".
+    The sum runs in dict order from zeros, like the reference."""
+    if stem not in stems:
+        raise KeyError(f"stem {stem!r} is not in the separated sources {list(stems)}")
+    res = dict(stems)
+    out = {}
+    if other_method == "minus":
+        out["minus_" + stem] = origin - res[stem]
+    out[stem] = res.pop(stem)
+    if other_method == "add":
+        other = torch.zeros_like(next(iter(res.values())))
+        for v in res.values():
+            other += v
+        out["no_" + stem] = other
+    elif other_method not in ("minus", "none"):
+        raise ValueError(f"Invalid other_method {other_method}")
+    return out
