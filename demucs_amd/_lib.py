@@ -59,9 +59,9 @@ SIGNATURES = {
     "mi_profile_end": (C.c_int, [C.c_void_p, C.POINTER(MiProfileRow), C.c_int32, C.POINTER(C.c_int32), C.c_void_p]),
     "mi_model_device_bytes": (C.c_int64, [C.c_void_p]),
     "mi_segments_gather": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
-                                     C.c_void_p]),
-    "mi_ola_accumulate": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
-                                    C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
+                                     C.c_int64, C.c_void_p]),
+    "mi_ola_accumulate": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p]),
     "mi_ola_finish": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32,
                                 C.c_int32, C.c_void_p, C.c_void_p]),
     "mi_stft_cac": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),

@@ -199,6 +199,18 @@ def apply_model(model, mix: Union[torch.Tensor, TensorChunk], shifts: int = 1, s
         pool = ThreadPoolExecutor(num_workers) if (num_workers > 0 and device.type == "cpu") else DummyPoolExecutor()
     if lock is None:
         lock = Lock()
+    if device.type == "cuda" and split and _is_engine(model) and isinstance(mix, torch.Tensor):
+        from . import distributed
+        if distributed.sharding_active():
+            # one process per GPU: every pass's segments are sharded over the ranks, ONE all-gather per call
+            out = distributed.apply_model_sharded(model, mix, shifts=shifts, overlap=overlap, transition_power=transition_power,
+                                                  segment=segment, device=device, callback=callback, callback_arg=callback_arg,
+                                                  lock=lock)
+            return out if mix.device == device else _to_host(out, device)
+    if device.type == "cuda" and mix.device.type == "cpu" and _is_engine(model):
+        return _apply_engine_from_host(model, mix, dict(
+            shifts=shifts, split=split, overlap=overlap, transition_power=transition_power, progress=progress, device=device,
+            num_workers=num_workers, segment=segment, pool=pool, lock=lock, callback=callback, callback_arg=callback_arg))
     callback_arg = _with(callback_arg, model_idx_in_bag=0, shift_idx=0, segment_offset=0)
     common: Dict[str, Any] = dict(shifts=shifts, split=split, overlap=overlap, transition_power=transition_power,
                                   progress=progress, device=device, pool=pool, segment=segment, lock=lock)
@@ -338,14 +350,41 @@ def _i32(values, device) -> torch.Tensor:
     return torch.tensor(list(values), dtype=torch.int32, device=device)
 
 
+def _is_engine(model) -> bool:
+    if isinstance(model, BagOfModels):
+        return all(_is_engine(m) for m in model.models)
+    return isinstance(model, HTDemucs)
+
+
+def _leaf_valid_length(model: HTDemucs, segment_length: int, segment) -> int:
+    """Length the leaf pads a chunk to (apply.py:305-310): int(segment * sr) with a segment override, else the
+    training length.  Raises the reference's error when it exceeds what the model was built for."""
+    valid = int(segment * model.samplerate) if segment is not None else model.valid_length(segment_length)
+    if valid > model.segment_length:
+        raise ValueError(f"Given length {valid} is longer than training length {model.segment_length}")
+    return valid
+
+
 def device_split_accumulate(model: HTDemucs, base: torch.Tensor, chunk_offset: int, length: int, offsets: Sequence[int],
                             segment_length: int, valid_length: int, weight: torch.Tensor, acc: torch.Tensor, acc_origin: int,
-                            on_segment: Optional[Callable[[int], None]] = None) -> None:
+                            on_start: Optional[Callable[[int], None]] = None, on_end: Optional[Callable[[int], None]] = None,
+                            draw_rng: bool = True, base_origin: int = 0) -> None:
     """Run the segments at `offsets` (relative to the chunk that starts at `chunk_offset` of the
     device-resident track `base` (channels, total) and is `length` long) and add
     `weight[:n] * center_trim(model(padded_i), n)` into `acc` (rows, acc_len), whose sample 0 is
     chunk position `acc_origin`.  One gather + one batched forward + one overlap-add per
-    `model.max_batch` segments.  `on_segment(offset)` is called once per segment, in order."""
+    `model.max_batch` segments.  `base` may be a WINDOW of the track whose sample 0 is track position
+    `base_origin` (multi-GPU ranks hold only their span + halo): positions outside the window read as
+    zero, exactly like positions outside the track, so the window must reach every sample the segments'
+    padded windows touch, or the real track end.
+    `on_start(offset)` / `on_end(offset)` bracket each segment's forward in the reference's event order
+    (start, end, start, end ...): the first `start` of a batch fires before the batched forward is
+    enqueued and no `end` fires before it."""
+    if valid_length > model.segment_length:
+        raise ValueError(f"Given length {valid_length} is longer than training length {model.segment_length}")
+    if segment_length > valid_length or weight.numel() < segment_length:
+        raise ValueError(f"segment length {segment_length} does not fit the padded length {valid_length} / the weight "
+                         f"ramp ({weight.numel()})")
     lib = _lib.load()
     dev = base.device
     channels, total = base.shape
@@ -356,32 +395,40 @@ def device_split_accumulate(model: HTDemucs, base: torch.Tensor, chunk_offset: i
     short = valid_length < SL          # right-padded with zeros like HTDemucs.forward does (htdemucs.py:534-537)
     seg_buf = torch.zeros(B, channels, SL, device=dev, dtype=torch.float32)
     cut_buf = torch.empty(B, channels, valid_length, device=dev, dtype=torch.float32) if short else seg_buf
-    out_buf = torch.empty(B, len(model.sources), channels, SL, device=dev, dtype=torch.float32)
+    out_buf = torch.empty(B, rows // channels, channels, SL, device=dev, dtype=torch.float32)
     with torch.cuda.device(dev):
         for i0 in range(0, len(offsets), B):
             offs = list(offsets[i0:i0 + B])
             nb = len(offs)
             lens = [min(length - o, segment_length) for o in offs]
             trims = [(valid_length - n) // 2 for n in lens]
-            starts = [chunk_offset + o - t for o, t in zip(offs, trims)]            # TensorChunk.padded window
+            starts = [chunk_offset + o - t - base_origin for o, t in zip(offs, trims)]     # TensorChunk.padded window
             # index tensors stay referenced until the launches below are enqueued: the caching allocator
             # may hand a dropped tensor's block to the next allocation before the kernel has read it
             t_starts = _i64(starts, dev)
             _lib.check(lib.mi_segments_gather(base.data_ptr(), total, channels, t_starts.data_ptr(), nb, valid_length,
-                                              cut_buf.data_ptr(), stream()), "mi_segments_gather")
+                                              cut_buf.data_ptr(), cut_buf.numel(), stream()), "mi_segments_gather")
             if short:
                 seg_buf[:nb, :, :valid_length] = cut_buf[:nb]
-            for o in offs:
-                random.randrange(1)                  # transformer.py:680, once per segment forward
-                if on_segment is not None:
-                    on_segment(o)
+            if on_start is not None:
+                on_start(offs[0])
             model.forward_segments(seg_buf[:nb], out_buf[:nb])
+            for k, o in enumerate(offs):
+                if draw_rng:
+                    random.randrange(1)              # transformer.py:680, once per segment forward (whole batch of tracks)
+                if k and on_start is not None:
+                    on_start(o)
+                if on_end is not None:
+                    on_end(o)
             acc_offs = [o - acc_origin for o in offs]
             t_offs, t_lens, t_trims = _i64(acc_offs, dev), _i32(lens, dev), _i32(trims, dev)
-            _lib.check(lib.mi_ola_accumulate(acc.data_ptr(), acc.shape[1], rows, out_buf.data_ptr(), SL,
-                                             t_offs.data_ptr(), t_lens.data_ptr(), t_trims.data_ptr(), nb, min(acc_offs),
-                                             max(a + n for a, n in zip(acc_offs, lens)), weight.data_ptr(), stream()),
-                       "mi_ola_accumulate")
+            # a segment may hang over either end of `acc` (a rank's slab of a shifted pass): only the part inside counts
+            span_lo, span_hi = max(0, min(acc_offs)), min(acc.shape[1], max(a + n for a, n in zip(acc_offs, lens)))
+            if span_hi <= span_lo:
+                continue
+            _lib.check(lib.mi_ola_accumulate(acc.data_ptr(), acc.shape[1], rows, out_buf.data_ptr(), SL, out_buf.numel(),
+                                             t_offs.data_ptr(), t_lens.data_ptr(), t_trims.data_ptr(), nb, span_lo,
+                                             span_hi, weight.data_ptr(), weight.numel(), stream()), "mi_ola_accumulate")
 
 
 def device_split_finish(acc: torch.Tensor, acc_origin: int, length: int, offsets: Sequence[int], segment_length: int,
@@ -402,36 +449,65 @@ def _apply_split_device(model: HTDemucs, mix, common, callback, callback_arg) ->
     chunk = tensor_chunk(mix)
     batch, channels, length = chunk.shape
     seg, segment_length, stride, offsets = _segment_plan(model, length, common["overlap"], common["segment"])
-    # the leaf pads to int(segment * sr) when a segment override is given, else to the training length
-    valid_length = int(common["segment"] * model.samplerate) if common["segment"] is not None else model.valid_length(segment_length)
-    if valid_length > model.segment_length:
-        raise ValueError(f"Given length {valid_length} is longer than training length {model.segment_length}")
+    valid_length = _leaf_valid_length(model, segment_length, common["segment"])
     weight = _transition_weight(segment_length, common["transition_power"], device).to(torch.float32).contiguous()
     S = len(model.sources)
-    out = torch.empty(batch, S, channels, length, device=mix.device, dtype=torch.float32)
-    iterator = offsets
+    on_device = mix.device == device
+    out = (torch.zeros if on_device else torch.empty)(batch, S, channels, length, device=mix.device, dtype=torch.float32)
     bar = None
     if common["progress"]:
         import tqdm
         scale = float(format(stride / model.samplerate, ".2f"))
-        bar = tqdm.tqdm(total=len(offsets) * batch, unit_scale=scale, ncols=120, unit="seconds")
+        bar = tqdm.tqdm(total=len(offsets), unit_scale=scale, ncols=120, unit="seconds")
 
-    def events(offset):
+    def on_start(offset):
         if callback is not None:
-            arg = _with(callback_arg, segment_offset=offset)
             with lock:
-                callback(_with(arg, state="start"))
+                callback(_with(callback_arg, segment_offset=offset, state="start"))
+
+    def on_end(offset):
+        if callback is not None:
             with lock:
-                callback(_with(arg, state="end"))
+                callback(_with(callback_arg, segment_offset=offset, state="end"))
         if bar is not None:
             bar.update(1)
 
     for b in range(batch):
+        # the reference forwards all `batch` tracks of a segment offset in ONE model call: one RNG draw and one
+        # start/end event pair per offset, not per (track, offset)
+        first = b == 0
         base = chunk.tensor[b].to(device=device, dtype=torch.float32).contiguous()       # whole track resident in HBM
-        acc = torch.zeros(S * channels, length, device=device, dtype=torch.float32)
-        device_split_accumulate(model, base, chunk.offset, length, iterator, segment_length, valid_length, weight, acc, 0, events)
+        acc = out[b].view(S * channels, length) if on_device else torch.zeros(S * channels, length, device=device, dtype=torch.float32)
+        device_split_accumulate(model, base, chunk.offset, length, offsets, segment_length, valid_length, weight, acc, 0,
+                                on_start if first else None, on_end if first else None, draw_rng=first)
         device_split_finish(acc, 0, length, offsets, segment_length, weight)
-        out[b] = acc.view(S, channels, length).to(mix.device)
+        if not on_device:
+            out[b] = acc.view(S, channels, length).to(mix.device)
     if bar is not None:
         bar.close()
     return out
+
+
+def _apply_engine_from_host(model, mix, kwargs) -> torch.Tensor:
+    """Host `mix`, GPU engine: ONE H2D of the mix, the whole bag / shift / split recursion on device-resident tensors
+    (averages accumulated in HBM), ONE D2H of the finished stems into a pinned host tensor.  Same result contract as the
+    reference: a new float32 tensor on `mix.device`."""
+    device = kwargs["device"]
+    chunk = tensor_chunk(mix)
+    src = chunk.tensor
+    with torch.cuda.device(device):
+        dev_src = src.to(device=device, dtype=torch.float32, non_blocking=True)
+        dev_mix = TensorChunk(dev_src, chunk.offset, chunk.length) if isinstance(mix, TensorChunk) else dev_src
+        out = apply_model(model, dev_mix, **kwargs)
+    # the reference builds the result on `mix.device` in the split branch only (apply.py:259); a bare leaf
+    # (and a shift average over bare leaves) stays on `device`
+    return _to_host(out, device) if kwargs["split"] else out
+
+
+def _to_host(out: torch.Tensor, device) -> torch.Tensor:
+    """Device result -> new pinned host tensor (one DMA at PCIe rate instead of a staged pageable copy)."""
+    with torch.cuda.device(device):
+        host = torch.empty(out.shape, dtype=torch.float32, pin_memory=True)
+        host.copy_(out, non_blocking=True)
+        torch.cuda.current_stream(device).synchronize()
+    return host

@@ -132,20 +132,30 @@ int mi_profile_end(void *handle, mi_profile_row *rows, int32_t max_rows, int32_t
     return MI_OK;
 }
 
-int64_t mi_model_device_bytes(void *handle) { return handle ? ((Model *)handle)->device_bytes : 0; }
+int64_t mi_model_device_bytes(void *handle) {
+    if (!handle) return 0;
+    Model *m = (Model *)handle;
+    return m->device_bytes + (m->ws ? m->ws->bytes : 0);       // weights + the (possibly shared) workspace
+}
 
 int mi_segments_gather(const float *track_dev, int64_t track_len, int32_t channels, const int64_t *starts_dev, int32_t B,
-                       int32_t valid, float *seg_dev, void *stream) {
+                       int32_t valid, float *seg_dev, int64_t seg_capacity, void *stream) {
     MI_REQUIRE(track_dev && starts_dev && seg_dev && B > 0 && valid > 0 && channels > 0, "mi_segments_gather: bad argument");
+    MI_REQUIRE((int64_t)B * channels * valid <= seg_capacity, "mi_segments_gather: %d x %d x %d floats do not fit seg_dev (%lld)", B,
+               channels, valid, (long long)seg_capacity);
     return launch_segments_gather(track_dev, track_len, channels, starts_dev, B, valid, seg_dev, (hipStream_t)stream);
 }
 
 int mi_ola_accumulate(float *acc_dev, int64_t acc_len, int32_t rows, const float *model_out_dev, int32_t valid,
-                      const int64_t *offs_dev, const int32_t *lens_dev, const int32_t *trim_dev, int32_t B, int64_t span_lo,
-                      int64_t span_hi, const float *weight_dev, void *stream) {
-    MI_REQUIRE(acc_dev && model_out_dev && offs_dev && lens_dev && trim_dev && weight_dev && B > 0, "mi_ola_accumulate: bad argument");
+                      int64_t out_capacity, const int64_t *offs_dev, const int32_t *lens_dev, const int32_t *trim_dev, int32_t B,
+                      int64_t span_lo, int64_t span_hi, const float *weight_dev, int32_t weight_len, void *stream) {
+    MI_REQUIRE(acc_dev && model_out_dev && offs_dev && lens_dev && trim_dev && weight_dev && B > 0 && rows > 0 && valid > 0 &&
+               weight_len > 0, "mi_ola_accumulate: bad argument");
+    MI_REQUIRE((int64_t)B * rows * valid <= out_capacity, "mi_ola_accumulate: %d x %d x %d floats exceed model_out_dev (%lld)", B, rows,
+               valid, (long long)out_capacity);
+    MI_REQUIRE(span_hi <= acc_len, "mi_ola_accumulate: span end %lld past the accumulator (%lld)", (long long)span_hi, (long long)acc_len);
     return launch_ola_accumulate(acc_dev, acc_len, rows, model_out_dev, valid, offs_dev, lens_dev, trim_dev, B, span_lo, span_hi,
-                                 weight_dev, (hipStream_t)stream);
+                                 weight_dev, weight_len, (hipStream_t)stream);
 }
 
 int mi_ola_finish(float *acc_dev, int64_t acc_len, int32_t rows, int64_t acc_off0, const int64_t *offs_dev,

@@ -69,7 +69,7 @@ int launch_segments_gather(const float *track, int64_t track_len, int channels, 
                            float *seg, hipStream_t st);
 int launch_ola_accumulate(float *acc, int64_t acc_len, int rows, const float *model_out, int valid, const int64_t *offs_dev,
                           const int32_t *lens_dev, const int32_t *trim_dev, int B, int64_t span_lo, int64_t span_hi,
-                          const float *weight, hipStream_t st);
+                          const float *weight, int weight_len, hipStream_t st);
 int launch_ola_finish(float *acc, int64_t acc_len, int rows, int64_t acc_off0, const int64_t *offs_dev, const int32_t *lens_dev,
                       int n_segments, int max_len, const float *weight, hipStream_t st);
 

@@ -1,5 +1,6 @@
 // Engine state: packed weights, gather tables, workspace.  One Model per (weights, device).
 #pragma once
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -67,7 +68,36 @@ struct Profiler {
     ~Profiler();
 };
 
-struct Model {
+// Activation workspace of one forward (sized for max_batch segments).  Handles created on the same device with the
+// same geometry SHARE one workspace (a bag of four fine-tuned models holds the ~0.57 GB per batched segment once,
+// not four times): such handles must not run concurrently -- they are used from one stream, one after the other,
+// which is what the bag loop of apply_model does.
+struct WorkspacePtrs {
+    float *w_xt0 = nullptr, *w_zt = nullptr, *w_x0 = nullptr;
+    float *w_skip[4] = {}, *w_skip_t[4] = {};
+    float *w_a = nullptr, *w_b = nullptr, *w_c = nullptr, *w_h = nullptr;
+    float *w_ta = nullptr, *w_tb = nullptr, *w_tc = nullptr, *w_th = nullptr;
+    float2 *w_tr_stat[2][2] = {}, *w_tr_stat1[2] = {};   // per-token (mean, rstd) of the layer inputs / of x1
+    float *w_tr_x[2][2] = {}, *w_tr_qkv[2] = {}, *w_tr_att[2] = {}, *w_tr_x1[2] = {},
+          *w_tr_x2[2] = {}, *w_tr_ffh[2] = {};
+    float *w_yspec = nullptr, *w_ytime = nullptr, *w_yt = nullptr, *w_fr = nullptr;
+    double *w_stats = nullptr, *w_stats_t = nullptr;
+    float2 *w_st1 = nullptr, *w_st2 = nullptr, *w_st1_t = nullptr, *w_st2_t = nullptr;
+    float2 *w_norm_f = nullptr, *w_denorm_f = nullptr, *w_norm_t = nullptr, *w_denorm_t = nullptr;
+};
+struct Workspace : WorkspacePtrs {
+    std::string key;
+    std::vector<void *> allocs;
+    int64_t bytes = 0;
+    size_t stats_bytes = 0;
+    // a forward that failed half-way may leave the self-cleaning statistics slots (norms.hip) non-zero: the next
+    // forward re-zeroes them first instead of silently mis-normalising every later call
+    bool dirty = false;
+    int alloc(void **p, size_t n);
+    ~Workspace();
+};
+
+struct Model : WorkspacePtrs {
     mi_config cfg{};
     Profiler prof;
     int conv(const mi_conv_desc &d, hipStream_t st);
@@ -88,24 +118,14 @@ struct Model {
     float *norm_in_w[2] = {}, *norm_in_b[2] = {}, *pos_emb[2] = {};
     TrLayerW tr[2][5];
 
-    // workspace (sized for cfg.max_batch)
-    float *w_xt0 = nullptr, *w_zt = nullptr, *w_x0 = nullptr;
-    float *w_skip[4] = {}, *w_skip_t[4] = {};
-    float *w_a = nullptr, *w_b = nullptr, *w_c = nullptr, *w_h = nullptr;
-    float *w_ta = nullptr, *w_tb = nullptr, *w_tc = nullptr, *w_th = nullptr;
-    float2 *w_tr_stat[2][2] = {}, *w_tr_stat1[2] = {};   // per-token (mean, rstd) of the layer inputs / of x1
-    float *w_tr_x[2][2] = {}, *w_tr_qkv[2] = {}, *w_tr_att[2] = {}, *w_tr_x1[2] = {},
-          *w_tr_x2[2] = {}, *w_tr_ffh[2] = {};
-    float *w_yspec = nullptr, *w_ytime = nullptr, *w_yt = nullptr, *w_fr = nullptr;
-    double *w_stats = nullptr, *w_stats_t = nullptr;
-    float2 *w_st1 = nullptr, *w_st2 = nullptr, *w_st1_t = nullptr, *w_st2_t = nullptr;
-    float2 *w_norm_f = nullptr, *w_denorm_f = nullptr, *w_norm_t = nullptr, *w_denorm_t = nullptr;
+    std::shared_ptr<Workspace> ws;   // activation workspace, shared by every handle with the same (device, geometry, max_batch)
 
     ~Model();
     int init(const mi_config &c, const mi_tensor_desc *weights, size_t n);
     int forward(const float *mix, float *out, int B, hipStream_t st);
     int forward_core(const float *mix, float *spec_out, float *time_out, int B, hipStream_t st);
     int run_core(const float *mix, int B, hipStream_t st);
+    int run_core_impl(const float *mix, int B, hipStream_t st);
 
    private:
     int dev_alloc(void **p, size_t bytes);
@@ -119,6 +139,7 @@ struct Model {
     int make_ktab(const Gather &g, int Kpad, mi_ktab_entry **out);
     int load_dconv(const WeightTable &wt, const std::string &prefix, int C, int64_t chan_stride, int D2, bool freq, DConvW *dw);
     int alloc_workspace();
+    int fill_workspace(Workspace &w);
     int run_dconv(const DConvW &w, int C, const Geo &g, float *x, float *tmp, float *hidden, double *stats, float2 *st1, float2 *st2,
                   hipStream_t st);
     int run_tr_layer(int br, int k, int B, const float *x, const float2 *xstat, const float *other, const float2 *ostat, float *out,

@@ -8,6 +8,8 @@
 // of transformer.py:653-654 is never materialised; the positional table is stored in our order).
 #include <cmath>
 #include <map>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -489,48 +491,85 @@ int Model::init(const mi_config &c, const mi_tensor_desc *weights, size_t n) {
 // ------------------------------------------------------------------------------------------------
 // workspace
 // ------------------------------------------------------------------------------------------------
+int Workspace::alloc(void **p, size_t n) {
+    n = (n + 255) & ~(size_t)255;
+    hipError_t e = hipMalloc(p, n);
+    if (e != hipSuccess) return set_error(MI_ENOMEM, "hipMalloc(%zu) failed: %s", n, hipGetErrorString(e));
+    allocs.push_back(*p);
+    bytes += (int64_t)n;
+    return MI_OK;
+}
+Workspace::~Workspace() {
+    for (void *p : allocs) (void)hipFree(p);
+}
+
+// process-wide registry: key -> live workspace (weak: freed with its last handle)
+static std::mutex g_ws_mutex;
+static std::map<std::string, std::weak_ptr<Workspace>> g_ws;
+
 int Model::alloc_workspace() {
+    int dev = 0;
+    MI_HIP(hipGetDevice(&dev));
+    char key[128];
+    snprintf(key, sizeof(key), "htdemucs dev%d S%d SL%d B%d", dev, S, SL, cfg.max_batch);
+    std::lock_guard<std::mutex> lock(g_ws_mutex);
+    auto it = g_ws.find(key);
+    if (it != g_ws.end()) ws = it->second.lock();
+    if (!ws) {
+        auto w = std::make_shared<Workspace>();
+        w->key = key;
+        MI_TRY(fill_workspace(*w));
+        g_ws[key] = w;
+        ws = w;
+    }
+    static_cast<WorkspacePtrs &>(*this) = *ws;
+    return MI_OK;
+}
+
+int Model::fill_workspace(Workspace &w) {
     const size_t B = cfg.max_batch;
-    auto A = [&](float **p, size_t per_item) { return dev_alloc((void **)p, per_item * B * sizeof(float)); };
-    MI_TRY(A(&w_xt0, (size_t)2 * SL));
-    MI_TRY(A(&w_zt, (size_t)4 * 2048 * T));
-    MI_TRY(A(&w_x0, (size_t)4 * 2048 * T));
+    auto A = [&](float **p, size_t per_item) { return w.alloc((void **)p, per_item * B * sizeof(float)); };
+    auto dev_alloc = [&](void **p, size_t n) { return w.alloc(p, n); };
+    MI_TRY(A(&w.w_xt0, (size_t)2 * SL));
+    MI_TRY(A(&w.w_zt, (size_t)4 * 2048 * T));
+    MI_TRY(A(&w.w_x0, (size_t)4 * 2048 * T));
     size_t big = 0;
     for (int i = 0; i < 4; ++i) {
         const size_t nf = (size_t)kCh[i] * kFr[i + 1] * T, nt = (size_t)kCh[i] * Lp[i + 1];
-        MI_TRY(A(&w_skip[i], nf)); MI_TRY(A(&w_skip_t[i], nt));
+        MI_TRY(A(&w.w_skip[i], nf)); MI_TRY(A(&w.w_skip_t[i], nt));
         big = std::max(big, std::max(nf, nt));
     }
     // scratch shared by all U-Net layers (largest layer: 48 x 512 x T)
-    MI_TRY(A(&w_a, big)); MI_TRY(A(&w_b, big)); MI_TRY(A(&w_c, big)); MI_TRY(A(&w_h, big / 2));
-    MI_TRY(A(&w_ta, big)); MI_TRY(A(&w_tb, big)); MI_TRY(A(&w_tc, big)); MI_TRY(A(&w_th, big / 2));
+    MI_TRY(A(&w.w_a, big)); MI_TRY(A(&w.w_b, big)); MI_TRY(A(&w.w_c, big)); MI_TRY(A(&w.w_h, big / 2));
+    MI_TRY(A(&w.w_ta, big)); MI_TRY(A(&w.w_tb, big)); MI_TRY(A(&w.w_tc, big)); MI_TRY(A(&w.w_th, big / 2));
     // DConv hidden tensors carry round_up(C/8, 16) channels; the padding channels must read as zero
-    MI_HIP(hipMemset(w_h, 0, (big / 2) * B * sizeof(float)));
-    MI_HIP(hipMemset(w_th, 0, (big / 2) * B * sizeof(float)));
+    MI_HIP(hipMemset(w.w_h, 0, (big / 2) * B * sizeof(float)));
+    MI_HIP(hipMemset(w.w_th, 0, (big / 2) * B * sizeof(float)));
     const size_t Tf = 8 * (size_t)T, Tt = Lt[4];
     for (int br = 0; br < 2; ++br) {
         const size_t P = br ? Tt : Tf;
-        MI_TRY(A(&w_tr_x[br][0], 512 * P)); MI_TRY(A(&w_tr_x[br][1], 512 * P));
-        for (int q = 0; q < 2; ++q) MI_TRY(dev_alloc((void **)&w_tr_stat[br][q], B * P * sizeof(float2)));
-        MI_TRY(dev_alloc((void **)&w_tr_stat1[br], B * P * sizeof(float2)));
-        MI_TRY(A(&w_tr_qkv[br], 1536 * Tf)) /* cross layers: Q (512 x Tq) + KV (1024 x Tk) */; MI_TRY(A(&w_tr_att[br], 512 * P));
-        MI_TRY(A(&w_tr_x1[br], 512 * P)); MI_TRY(A(&w_tr_x2[br], 512 * P)); MI_TRY(A(&w_tr_ffh[br], 2048 * P));
+        MI_TRY(A(&w.w_tr_x[br][0], 512 * P)); MI_TRY(A(&w.w_tr_x[br][1], 512 * P));
+        for (int q = 0; q < 2; ++q) MI_TRY(dev_alloc((void **)&w.w_tr_stat[br][q], B * P * sizeof(float2)));
+        MI_TRY(dev_alloc((void **)&w.w_tr_stat1[br], B * P * sizeof(float2)));
+        MI_TRY(A(&w.w_tr_qkv[br], 1536 * Tf)) /* cross layers: Q (512 x Tq) + KV (1024 x Tk) */; MI_TRY(A(&w.w_tr_att[br], 512 * P));
+        MI_TRY(A(&w.w_tr_x1[br], 512 * P)); MI_TRY(A(&w.w_tr_x2[br], 512 * P)); MI_TRY(A(&w.w_tr_ffh[br], 2048 * P));
     }
-    MI_TRY(A(&w_yspec, (size_t)4 * S * 2048 * T));
-    MI_TRY(A(&w_ytime, (size_t)2 * S * SL));
-    MI_TRY(A(&w_yt, (size_t)4 * S * 2048 * T));
-    MI_TRY(A(&w_fr, (size_t)S * T * 2 * 4096));
+    MI_TRY(A(&w.w_yspec, (size_t)4 * S * 2048 * T));
+    MI_TRY(A(&w.w_ytime, (size_t)2 * S * SL));
+    MI_TRY(A(&w.w_yt, (size_t)4 * S * 2048 * T));
+    MI_TRY(A(&w.w_fr, (size_t)S * T * 2 * 4096));
     const size_t max_rows = B * 512;
-    MI_TRY(dev_alloc((void **)&w_stats, max_rows * kStatSlots * 2 * sizeof(double)));
-    MI_TRY(dev_alloc((void **)&w_stats_t, max_rows * kStatSlots * 2 * sizeof(double)));
-    MI_HIP(hipMemset(w_stats, 0, max_rows * kStatSlots * 2 * sizeof(double)));      // finalize_stats re-zeroes after each use
-    MI_HIP(hipMemset(w_stats_t, 0, max_rows * kStatSlots * 2 * sizeof(double)));
-    MI_TRY(dev_alloc((void **)&w_st1, max_rows * sizeof(float2)));
-    MI_TRY(dev_alloc((void **)&w_st2, max_rows * sizeof(float2)));
-    MI_TRY(dev_alloc((void **)&w_st1_t, max_rows * sizeof(float2)));
-    MI_TRY(dev_alloc((void **)&w_st2_t, max_rows * sizeof(float2)));
-    MI_TRY(dev_alloc((void **)&w_norm_f, B * sizeof(float2))); MI_TRY(dev_alloc((void **)&w_denorm_f, B * sizeof(float2)));
-    MI_TRY(dev_alloc((void **)&w_norm_t, B * sizeof(float2))); MI_TRY(dev_alloc((void **)&w_denorm_t, B * sizeof(float2)));
+    w.stats_bytes = max_rows * kStatSlots * 2 * sizeof(double);
+    MI_TRY(dev_alloc((void **)&w.w_stats, w.stats_bytes));
+    MI_TRY(dev_alloc((void **)&w.w_stats_t, w.stats_bytes));
+    MI_HIP(hipMemset(w.w_stats, 0, w.stats_bytes));      // finalize_stats re-zeroes after each use
+    MI_HIP(hipMemset(w.w_stats_t, 0, w.stats_bytes));
+    MI_TRY(dev_alloc((void **)&w.w_st1, max_rows * sizeof(float2)));
+    MI_TRY(dev_alloc((void **)&w.w_st2, max_rows * sizeof(float2)));
+    MI_TRY(dev_alloc((void **)&w.w_st1_t, max_rows * sizeof(float2)));
+    MI_TRY(dev_alloc((void **)&w.w_st2_t, max_rows * sizeof(float2)));
+    MI_TRY(dev_alloc((void **)&w.w_norm_f, B * sizeof(float2))); MI_TRY(dev_alloc((void **)&w.w_denorm_f, B * sizeof(float2)));
+    MI_TRY(dev_alloc((void **)&w.w_norm_t, B * sizeof(float2))); MI_TRY(dev_alloc((void **)&w.w_denorm_t, B * sizeof(float2)));
     return MI_OK;
 }
 
@@ -672,6 +711,18 @@ int Model::run_tr_layer(int br, int k, int B, const float *x, const float2 *xsta
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
+// run_core with the "statistics slots may be dirty" bookkeeping of the (possibly shared) workspace
+int Model::run_core(const float *mix, int B, hipStream_t st) {
+    if (ws->dirty) {
+        MI_HIP(hipMemsetAsync(w_stats, 0, ws->stats_bytes, st));
+        MI_HIP(hipMemsetAsync(w_stats_t, 0, ws->stats_bytes, st));
+        ws->dirty = false;
+    }
+    const int r = run_core_impl(mix, B, st);
+    if (r != MI_OK) ws->dirty = true;
+    return r;
+}
+
 int Model::forward(const float *mix, float *out, int B, hipStream_t st) {
     MI_REQUIRE(mix && out, "forward: null buffer");
     MI_TRY(run_core(mix, B, st));
@@ -692,7 +743,7 @@ int Model::forward_core(const float *mix, float *spec_out, float *time_out, int 
 }
 
 // everything up to the decoder outputs: leaves w_yspec / w_ytime and the (mean, std) pairs in the workspace
-int Model::run_core(const float *mix, int B, hipStream_t st) {
+int Model::run_core_impl(const float *mix, int B, hipStream_t st) {
     MI_REQUIRE(B >= 1 && B <= cfg.max_batch, "forward: batch %d outside [1, %d]", B, cfg.max_batch);
     const int Tf = 8 * T, Tt = Lt[4];
     // ---- input statistics and normalisation (htdemucs.py:545-554) --------------------------------

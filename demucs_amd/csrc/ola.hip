@@ -26,7 +26,8 @@ __global__ __launch_bounds__(256) void segments_gather_kernel(const float *__res
 __global__ __launch_bounds__(256) void ola_accumulate_kernel(float *__restrict__ acc, int64_t acc_len, const float *__restrict__ mo,
                                                              int rows, int valid, const int64_t *__restrict__ offs,
                                                              const int32_t *__restrict__ lens, const int32_t *__restrict__ trim, int B,
-                                                             int64_t span_lo, int64_t span_hi, const float *__restrict__ weight) {
+                                                             int64_t span_lo, int64_t span_hi, const float *__restrict__ weight,
+                                                             int weight_len) {
     // the items that overlap this workgroup's 256 positions, in ascending item order (= the reference's summation
     // order), found once per workgroup instead of B range checks per sample
     __shared__ int n_hit;
@@ -55,8 +56,10 @@ __global__ __launch_bounds__(256) void ola_accumulate_kernel(float *__restrict__
     for (int h = 0; h < nh; ++h) {
         const int i = hit[h];
         const int64_t j = p - offs[i];
-        if (j >= 0 && j < lens[i]) {
-            const float v = mo[((size_t)i * rows + row) * valid + trim[i] + j];
+        // lens / trim are device arrays the host cannot validate without a sync: clamp to the buffers' extents
+        const int64_t src = trim[i] + j;
+        if (j >= 0 && j < lens[i] && j < weight_len && src >= 0 && src < valid) {
+            const float v = mo[((size_t)i * rows + row) * valid + src];
             a = __fadd_rn(a, __fmul_rn(weight[j], v));
             touched = true;
         }
@@ -85,7 +88,7 @@ __global__ __launch_bounds__(256) void ola_finish_kernel(float *__restrict__ acc
     float sw = 0.f;
     for (int i = lo; i < n && offs[i] <= p; ++i) {
         const int64_t j = p - offs[i];
-        if (j < lens[i]) sw = __fadd_rn(sw, weight[j]);
+        if (j < lens[i] && j < max_len) sw = __fadd_rn(sw, weight[j]);
     }
     const size_t idx = (size_t)blockIdx.y * acc_len + q;
     acc[idx] = __fdiv_rn(acc[idx], sw);
@@ -101,11 +104,11 @@ int launch_segments_gather(const float *track, int64_t track_len, int channels, 
 
 int launch_ola_accumulate(float *acc, int64_t acc_len, int rows, const float *model_out, int valid, const int64_t *offs_dev,
                           const int32_t *lens_dev, const int32_t *trim_dev, int B, int64_t span_lo, int64_t span_hi,
-                          const float *weight, hipStream_t st) {
+                          const float *weight, int weight_len, hipStream_t st) {
     MI_REQUIRE(span_hi > span_lo && span_lo >= 0, "ola: empty span");
     MI_REQUIRE(B >= 1 && B <= 256, "ola: %d segments per call (at most 256)", B);
     hipLaunchKernelGGL(ola_accumulate_kernel, dim3(ceil_div(span_hi - span_lo, 256), rows), dim3(256), 0, st, acc, acc_len, model_out,
-                       rows, valid, offs_dev, lens_dev, trim_dev, B, span_lo, span_hi, weight);
+                       rows, valid, offs_dev, lens_dev, trim_dev, B, span_lo, span_hi, weight, weight_len);
     MI_CHECK_LAUNCH();
     return MI_OK;
 }

@@ -21,7 +21,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .weights import HTDemucsConfig, htdemucs_schema
+from .weights import HTDemucsConfig, check_reference_keyword, htdemucs_schema
 
 __all__ = ["HTDemucs"]
 
@@ -30,11 +30,10 @@ class HTDemucs:
     def __init__(self, sources: List[str], segment=Fraction(39, 5), max_batch: int = 8, **kwargs):
         cfg = HTDemucsConfig(sources=list(sources), segment=Fraction(segment) if not isinstance(segment, Fraction) else segment)
         for k, v in kwargs.items():            # accept the reference's keyword names, reject other architectures
-            if not hasattr(cfg, k):
-                if k in ("t_dropout", "rescale", "dconv_init"):   # training-only knobs, irrelevant in eval
-                    continue
+            if hasattr(cfg, k):
+                setattr(cfg, k, v)
+            elif not check_reference_keyword(k, v, cfg.depth):    # raises when the value selects another architecture
                 raise ValueError(f"unsupported HTDemucs argument {k!r}")
-            setattr(cfg, k, v)
         cfg.validate()
         self.cfg = cfg
         self.sources = list(sources)
@@ -45,7 +44,7 @@ class HTDemucs:
         self.max_batch = int(max_batch)
         self._schema = htdemucs_schema(cfg)
         self._state: Optional["OrderedDict[str, np.ndarray]"] = None
-        self._handle: Optional[int] = None
+        self._handles: Dict[torch.device, int] = {}      # engine handle per GPU the model has been used on
         self._device: Optional[torch.device] = None
         self.training = False
 
@@ -94,9 +93,10 @@ class HTDemucs:
         device = torch.device(device)
         if device.type == "cuda" and device.index is None:
             device = torch.device("cuda", torch.cuda.current_device())
-        if device != self._device:
-            self._release()
-            self._device = device
+        # Engine handles are cached per device: `apply_model` moves every sub-model of a bag to the compute device and
+        # back to its "home" on each call (apply.py:213-218); re-packing 42 M weights each time would dominate.
+        # `release()` frees them explicitly.
+        self._device = device
         return self
 
     def valid_length(self, length: int) -> int:
@@ -112,9 +112,14 @@ class HTDemucs:
 
     # ---- engine handle ------------------------------------------------------------------------
     def _release(self):
-        if self._handle is not None:
-            _lib.load().mi_model_destroy(C.c_void_p(self._handle))
-            self._handle = None
+        handles, self._handles = self._handles, {}
+        for dev, h in handles.items():
+            with torch.cuda.device(dev):
+                _lib.load().mi_model_destroy(C.c_void_p(h))
+
+    def release(self):
+        """Free the packed weights (and, with the last handle of its kind, the shared workspace) on every GPU."""
+        self._release()
 
     def __del__(self):
         try:
@@ -123,8 +128,8 @@ class HTDemucs:
             pass
 
     def _ensure_handle(self) -> int:
-        if self._handle is not None:
-            return self._handle
+        if self._device in self._handles:
+            return self._handles[self._device]
         if self._state is None:
             raise RuntimeError("HTDemucs has no weights: call load_state_dict first")
         if self._device is None or self._device.type != "cuda":
@@ -142,8 +147,8 @@ class HTDemucs:
         h = C.c_void_p()
         with torch.cuda.device(self._device):
             _lib.check(lib.mi_model_create(C.byref(cfg), descs, len(names), C.byref(h)), "mi_model_create")
-        self._handle = h.value
-        return self._handle
+        self._handles[self._device] = h.value
+        return h.value
 
     def set_max_batch(self, max_batch: int):
         if max_batch != self.max_batch:

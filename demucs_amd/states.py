@@ -11,7 +11,6 @@ the same format by the tests (tests/test_states.py).
 """
 from __future__ import annotations
 
-import inspect
 import warnings
 from fractions import Fraction
 from pathlib import Path
@@ -20,6 +19,7 @@ from typing import Union
 import torch
 
 from .htdemucs import HTDemucs
+from .weights import REFERENCE_DEFAULTS, check_reference_keyword
 
 #: qualified names of the reference classes a package may name -> engine class that takes the same keywords
 SUPPORTED = {"demucs.htdemucs.HTDemucs": HTDemucs}
@@ -67,13 +67,26 @@ def load_model(path_or_package, strict: bool = False, max_batch: int = 8) -> HTD
         raise ValueError(f"checkpoint class {qual} is not implemented by the MI355X engine (supported: {sorted(SUPPORTED)})")
     klass = SUPPORTED[qual]
     args, kwargs = tuple(package["args"]), dict(package["kwargs"])
-    if not strict:
-        ref_only = ("t_dropout", "rescale", "dconv_init")          # accepted and ignored by the engine class
-        cfg_fields = set(inspect.signature(klass).parameters) | set(vars(klass(["_"]).cfg)) | set(ref_only)
-        for key in list(kwargs):
-            if key not in cfg_fields:
-                warnings.warn("Dropping inexistant parameter " + key)
-                del kwargs[key]
+    cfg_fields = set(vars(klass(["_"]).cfg))
+    for key in list(kwargs):
+        if key in cfg_fields or key == "sources":
+            continue
+        # a reference keyword outside the engine's config: honoured by construction (dropped silently) or a
+        # ValueError when its value selects an architecture the engine does not implement -- never dropped blindly,
+        # because load_state_dict cannot notice flags that keep every tensor shape (t_cross_first, t_norm_first, ...)
+        if check_reference_keyword(key, kwargs[key], kwargs.get("depth", REFERENCE_DEFAULTS["depth"])):
+            del kwargs[key]
+        elif strict:
+            raise ValueError(f"unknown HTDemucs keyword {key!r} in the checkpoint package")
+        else:                                   # unknown to the reference's constructor too: its warn-and-drop rule
+            warnings.warn("Dropping inexistant parameter " + key)
+            del kwargs[key]
+    # keywords the package omits mean the REFERENCE's defaults (segment=10, dconv_mode=1, bottom_channels=0, ...),
+    # not the released-model values the engine class defaults to
+    if len(args) > 1:
+        raise ValueError("checkpoint package passes HTDemucs hyper-parameters positionally; only `sources` may be positional")
+    for key, default in REFERENCE_DEFAULTS.items():
+        kwargs.setdefault(key, default)
     model = klass(*args, max_batch=max_batch, **kwargs)
     set_state(model, package["state"])
     return model

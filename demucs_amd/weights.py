@@ -24,7 +24,7 @@ from typing import Dict, List, Tuple
 import numpy as np
 
 __all__ = ["HTDemucsConfig", "htdemucs_schema", "synthetic_state_dict", "counter_uniform",
-           "counter_normal"]
+           "counter_normal", "REFERENCE_DEFAULTS", "ENGINE_FIXED", "INERT_KEYWORDS", "check_reference_keyword"]
 
 
 @dataclass
@@ -71,6 +71,8 @@ class HTDemucsConfig:
         if self.bottom_channels != 512: bad.append("bottom_channels")
         if self.t_layers != 5 or self.t_heads != 8 or self.t_hidden_scale != 4.0: bad.append("t_*")
         if self.samplerate != 44100: bad.append("samplerate")
+        if float(self.freq_emb) != 0.2 or float(self.emb_scale) != 10.0: bad.append("freq_emb/emb_scale")
+        if float(self.t_max_period) != 10000.0 or float(self.t_weight_pos_embed) != 1.0: bad.append("t_max_period/t_weight_pos_embed")
         if len(self.sources) < 1 or len(self.sources) > 8: bad.append("sources")
         if bad:
             raise ValueError("unsupported HTDemucs hyper-parameters for the MI355X path: " + ", ".join(bad))
@@ -78,6 +80,55 @@ class HTDemucsConfig:
     @property
     def segment_length(self) -> int:
         return int(self.samplerate * self.segment)
+
+
+# ---------------------------------------------------------------------------------------
+# Every keyword of the reference constructor (demucs/htdemucs.py:56-133) that is NOT a field
+# of HTDemucsConfig, sorted by what it means for the engine.
+# ---------------------------------------------------------------------------------------
+#: defaults of the reference constructor for the HTDemucsConfig fields (a checkpoint package that omits a
+#: keyword means THIS value, not the released-model value the engine class defaults to)
+REFERENCE_DEFAULTS = dict(audio_channels=2, channels=48, growth=2, nfft=4096, depth=4, freq_emb=0.2, emb_scale=10,
+                          kernel_size=8, stride=4, context=1, dconv_mode=1, dconv_depth=2, dconv_comp=8,
+                          bottom_channels=0, t_layers=5, t_hidden_scale=4.0, t_heads=8, t_max_period=10000.0,
+                          t_weight_pos_embed=1.0, samplerate=44100, segment=10)
+
+#: keywords whose value changes the forward: the engine hard-codes the value on the right (the released htdemucs
+#: family, conf/config.yaml:195-271) and refuses anything else
+ENGINE_FIXED = dict(channels_time=None, cac=True, rewrite=True, multi_freqs=None, time_stride=2, context_enc=0,
+                    t_emb="sin", t_norm_in=True, t_norm_in_group=False, t_group_norm=False, t_norm_first=True,
+                    t_norm_out=True, t_layer_scale=True, t_gelu=True, t_sin_random_shift=0,
+                    t_sparse_self_attn=False, t_sparse_cross_attn=False, t_cross_first=False, use_train_segment=True)
+
+#: keywords that cannot change an eval-mode forward of the architecture above (training knobs, initialisation, and
+#: parameters of code paths that ENGINE_FIXED switches off): accepted with any value
+INERT_KEYWORDS = frozenset((
+    "t_dropout", "rescale", "dconv_init", "t_weight_decay", "t_lr", "emb_smooth",            # training / init only
+    "wiener_iters", "end_iters", "wiener_residual",                                          # unused when cac=True
+    "multi_freqs_depth",                                                                     # unused without multi_freqs
+    "norm_groups",                                                                           # unused: norm_starts >= depth
+    "t_max_positions", "t_cape_mean_normalize", "t_cape_augment", "t_cape_glob_loc_scale",   # t_emb != "sin" only
+    "t_mask_type", "t_mask_random_seed", "t_sparse_attn_window", "t_global_window", "t_sparsity", "t_auto_sparsity"))
+
+
+def check_reference_keyword(key: str, value, depth: int = 4) -> bool:
+    """True if `key` is a reference keyword outside HTDemucsConfig that the engine honours by construction (drop it
+    silently); raises ValueError when its value selects an architecture the engine does not implement; False for a
+    name unknown to the reference as well."""
+    if key in INERT_KEYWORDS:
+        return True
+    if key == "norm_starts":                      # GroupNorm inside HEnc/HDecLayer from this layer on: never, or refuse
+        if value < depth:
+            raise ValueError(f"unsupported HTDemucs argument norm_starts={value!r} (< depth {depth}: the engine has no "
+                             "in-layer GroupNorm)")
+        return True
+    if key in ENGINE_FIXED:
+        want = ENGINE_FIXED[key]
+        same = (value == want) or (key == "multi_freqs" and not value)
+        if not same:
+            raise ValueError(f"unsupported HTDemucs argument {key}={value!r}: the MI355X engine implements {key}={want!r}")
+        return True
+    return False
 
 
 def htdemucs_schema(cfg: HTDemucsConfig) -> "OrderedDict[str, Tuple[int, ...]]":

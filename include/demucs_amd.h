@@ -95,9 +95,10 @@ int64_t mi_model_device_bytes(void *handle);
  *
  * mi_segments_gather: TensorChunk.padded for a batch of segments.  For item i the segment is
  *   the `valid`-long window starting at track sample starts[i] (may be negative / run past the
- *   end: zero filled) of track_dev (channels, track_len); seg_dev is (B, channels, valid). */
+ *   end: zero filled) of track_dev (channels, track_len); seg_dev is (B, channels, valid) and holds seg_capacity
+ *   floats (checked: the call fails instead of writing past the buffer). */
 int mi_segments_gather(const float *track_dev, int64_t track_len, int32_t channels, const int64_t *starts_idx_dev,
-                       int32_t B, int32_t valid, float *seg_dev, void *stream);
+                       int32_t B, int32_t valid, float *seg_dev, int64_t seg_capacity, void *stream);
 
 /* mi_ola_accumulate: `out[..., off:off+SL] += weight[:n] * chunk_out` for a batch
  *   (demucs/apply.py:295-296) with chunk_out = center_trim(model_out, n) (utils.py:38-54).
@@ -105,10 +106,13 @@ int mi_segments_gather(const float *track_dev, int64_t track_len, int32_t channe
  *   [trim[i], trim[i]+lens[i]) of its rows, weighted by weight_dev[0:lens[i]], to
  *   acc_dev (rows, acc_len) at acc position offs[i].  [span_lo, span_hi) is the union of the
  *   items' acc ranges.  Items are applied in index order with separately rounded float32
- *   product and sum, i.e. exactly the reference's sequential loop. */
+ *   product and sum, i.e. exactly the reference's sequential loop.  model_out_dev holds out_capacity floats and
+ *   weight_dev weight_len floats: the host-visible extents are checked, and because lens / trim live on the device
+ *   the kernel itself never reads model_out_dev beyond `valid` per row nor weight_dev beyond weight_len. */
 int mi_ola_accumulate(float *acc_dev, int64_t acc_len, int32_t rows, const float *model_out_dev, int32_t valid,
-                      const int64_t *offs_idx_dev, const int32_t *lens_idx_dev, const int32_t *trim_idx_dev, int32_t B,
-                      int64_t span_lo, int64_t span_hi, const float *weight_dev, void *stream);
+                      int64_t out_capacity, const int64_t *offs_idx_dev, const int32_t *lens_idx_dev,
+                      const int32_t *trim_idx_dev, int32_t B, int64_t span_lo, int64_t span_hi, const float *weight_dev,
+                      int32_t weight_len, void *stream);
 
 /* mi_ola_finish: `out /= sum_weight` (demucs/apply.py:297-299); sum_weight is rebuilt from the
  *   (offs, lens) list of ALL segments of the track (sorted by offset, track coordinates) in the

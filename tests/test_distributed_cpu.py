@@ -20,32 +20,72 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, length, overlap, out_path):
+def _worker(rank, world, port, length, overlap, out_path, case):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    import random
     from demucs_amd import apply as P
-    from demucs_amd.distributed import apply_model_sharded
+    from demucs_amd.distributed import apply_model_sharded, no_sharding
     from test_apply_host import ToyModel
-    mix = torch.randn(1, 2, length, generator=torch.Generator().manual_seed(7))
-    got = apply_model_sharded(ToyModel(), mix, overlap=overlap)
-    want = P.apply_model(ToyModel(), mix, shifts=0, split=True, overlap=overlap)
-    ok = torch.equal(got, want)
+    batch = 2 if case == "batch2" else 1
+    mix = torch.randn(batch, 2, length, generator=torch.Generator().manual_seed(7))
+    events = []
+    if case in ("plain", "batch2"):
+        got = apply_model_sharded(ToyModel(), mix, overlap=overlap, callback=lambda d: events.append(dict(d)))
+        want = P.apply_model(ToyModel(), mix, shifts=0, split=True, overlap=overlap)
+        ok = torch.equal(got, want)                        # single pass: bit-identical
+        ok = ok and all(e["state"] in ("start", "end") for e in events) and len(events) % 2 == 0
+    else:
+        w = [[1.0, 0.0, 0.5], [0.0, 1.0, 1.5]]
+        make = (lambda: P.BagOfModels([ToyModel(1.0), ToyModel(0.7)], w)) if case == "bag_shifts" else (lambda: ToyModel())
+        if rank == 1:
+            random.seed(99)        # ranks that were NOT seeded alike still agree on the shift offsets (rank 0's are used)
+        else:
+            random.seed(5)
+        got = apply_model_sharded(make(), mix, shifts=2, overlap=overlap, callback=lambda d: events.append(dict(d)))
+        state_after = random.getstate()
+        random.seed(5)
+        with no_sharding():
+            want = P.apply_model(make(), mix, shifts=2, split=True, overlap=overlap)
+        # several passes: identical up to the last bit at the seams between two ranks' slabs
+        ok = bool((got - want).abs().max() <= 2e-6) and got.shape == want.shape
+        if rank == 0:              # a seeded rank consumed exactly the draws of the single-process run
+            ok = ok and state_after == random.getstate()
+        if case == "bag_shifts":
+            ok = ok and {e["model_idx_in_bag"] for e in events} <= {0, 1} and all(e["models"] == 2 for e in events)
     flags = [None] * world
-    dist.all_gather_object(flags, ok)
+    dist.all_gather_object(flags, bool(ok))
+    counts = [None] * world
+    dist.all_gather_object(counts, len(events))
     if rank == 0:
-        torch.save(dict(ok=all(flags), shape=tuple(got.shape)), out_path)
+        torch.save(dict(ok=all(flags), flags=flags, shape=tuple(got.shape), events=sum(counts)), out_path)
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,length,overlap", [(2, 2500, 0.25), (2, 300, 0.25), (3, 4001, 0.1)])
-def test_sharded_equals_single_process(tmp_path, world, length, overlap):
+@pytest.mark.parametrize("world,length,overlap,case", [
+    (2, 2500, 0.25, "plain"), (2, 300, 0.25, "plain"), (3, 4001, 0.1, "plain"), (2, 1700, 0.25, "batch2"),
+    (2, 2500, 0.25, "shifts"), (3, 3111, 0.25, "bag_shifts"), (2, 390, 0.25, "bag_shifts")])
+def test_sharded_equals_single_process(tmp_path, world, length, overlap, case):
     out_path = str(tmp_path / "res.pt")
-    mp.spawn(_worker, args=(world, _free_port(), length, overlap, out_path), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), length, overlap, out_path, case), nprocs=world, join=True)
     res = torch.load(out_path)
-    assert res["ok"] and res["shape"] == (1, 3, 2, length)
+    assert res["ok"], res
+    assert res["shape"] == (2 if case == "batch2" else 1, 3, 2, length)
+    if case in ("plain", "batch2"):       # every segment fired its start/end pair on exactly one rank
+        assert res["events"] == 2 * len(range(0, length, int((1 - overlap) * 400)))
+
+
+def test_track_intervals_cover_the_track_once():
+    from demucs_amd.distributed import track_intervals
+    for length, stride, world in [(7938000, 257985, 8), (158760000, 257985, 8), (300, 300, 2), (1000, 300, 3), (5, 300, 4)]:
+        iv = track_intervals(length, stride, world)
+        assert iv[0][0] == 0 and max(b for _, b in iv) == length
+        for (a0, b0), (a1, b1) in zip(iv, iv[1:]):
+            assert b0 == a1 or (a1 == b1 == length)
+        assert all(a % stride == 0 or a == length for a, _ in iv)
 
 
 def test_shard_ranges():

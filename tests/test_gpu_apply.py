@@ -53,7 +53,7 @@ def test_apply_model_matches_reference(golden, name):
     events = []
     out = P.apply_model(model, mix, device="cuda", callback=lambda d: events.append(dict(d)), **kw)
     # the split branch returns on mix.device; the bare leaf returns on `device` (apply.py:259,312-322)
-    assert out.device.type == ("cpu" if kw.get("split", True) or kw.get("shifts", 1) else "cuda")
+    assert out.device.type == ("cpu" if kw.get("split", True) else "cuda")
     out = out.cpu()
     assert out.dtype == torch.float32 and torch.equal(mix, mix0)
     e64 = g.check("f64", "out", out, atol=TOL)
@@ -145,4 +145,75 @@ def test_full_size_track_properties():
             want = O.htdemucs_forward(osd, seg, 4)
         lo, hi = SL - stride, stride                   # samples covered by segment k only (weight ratio = 1)
         err = (out[..., off + lo:off + hi].cpu().double() - want[..., lo:hi]).abs().max().item()
+        assert err <= TOL, (k, err)
+
+
+def _bag4(max_batch, wrap=lambda m: m):
+    cfg = HTDemucsConfig()
+    models = []
+    for seed in (10, 11, 12, 13):
+        m = HTDemucs(cfg.sources, max_batch=max_batch)
+        m.load_state_dict(synthetic_state_dict(cfg, seed))
+        models.append(wrap(m.to("cuda")))
+    onehot = [[1.0 if i == k else 0.0 for k in range(4)] for i in range(4)]          # remote/htdemucs_ft.yaml
+    return P.BagOfModels(models, onehot)
+
+
+def test_config3_full_size_bag_of_4_shifts_2():
+    """BASELINE configs[2] at full size in float32: bag of 4 (one-hot weights, distinct weights), shifts=2, the 3-minute
+    track handed over on the HOST, models already on the GPU: 4 x 2 x 31..32 segment forwards.  The device route (one
+    H2D, batched forwards, averages in HBM, one D2H) must equal the reference-ordered per-segment route bit for bit,
+    leave `mix` untouched, and each source must come from its own bag member."""
+    length = 180 * 44100
+    mix = torch.from_numpy(synth_mix(1, length, "noise"))[None]
+    mix0 = mix.clone()
+    bag = _bag4(32)
+    random.seed(0)
+    out = P.apply_model(bag, mix, shifts=2, overlap=0.25, device="cuda")
+    state = random.getstate()
+    assert out.device.type == "cpu" and out.shape == (1, 4, 2, length) and bool(torch.isfinite(out).all())
+    assert torch.equal(mix, mix0)
+    random.seed(0)
+    slow = P.apply_model(_bag4(4, PerSegment), mix.cuda(), shifts=2, overlap=0.25, device="cuda")
+    assert random.getstate() == state                       # same number of RNG draws in the same order
+    assert torch.equal(out, slow.cpu())
+    # one-hot weights: source k is exactly member k's own shift-averaged estimate
+    random.seed(0)
+    solo = P.apply_model(bag.models[0], mix, shifts=2, overlap=0.25, device="cuda")
+    assert torch.equal(out[:, 0], solo[:, 0])
+
+
+def test_config4_sixty_minute_track_single_gpu():
+    """BASELINE configs[3]'s track on ONE GPU: L = 158 760 000 samples, 616 segments (apply.py:264-266 arithmetic).
+    Finite, bit-identical to the per-segment route, two interior segments agree with the float64 oracle."""
+    from oracle import htdemucs_oracle as O
+    cfg = HTDemucsConfig()
+    sd = synthetic_state_dict(cfg, 0)
+    m = HTDemucs(cfg.sources, max_batch=32)
+    m.load_state_dict(sd)
+    length = 3600 * 44100
+    stride = int(0.75 * SL)
+    assert len(range(0, length, stride)) == 616
+    gen = torch.Generator(device="cuda").manual_seed(4)
+    mix = torch.randn(1, 2, length, device="cuda", generator=gen) * 0.1
+    out = P.apply_model(m, mix, shifts=0, overlap=0.25)
+    assert out.shape == (1, 4, 2, length) and out.device.type == "cuda"
+    assert bool(torch.isfinite(out[0, :, :, ::13]).all())
+    m2 = HTDemucs(cfg.sources, max_batch=4)
+    m2.load_state_dict(sd)
+    slow = P.apply_model(PerSegment(m2), mix, shifts=0, overlap=0.25)
+    assert torch.equal(out, slow)
+    del slow
+    osd = O.to_torch_state(sd, torch.float64)
+    for k in (0, 615, 333):
+        off = k * stride
+        n = min(SL, length - off)
+        lo, hi = (0 if k == 0 else SL - stride), min(stride, n)      # samples covered by segment k only
+        if hi - lo < 1000:
+            continue
+        seg = P.TensorChunk(mix, off, SL).padded(SL).cpu().double()       # the leaf's centred, neighbour-filled window
+        with torch.no_grad():
+            want = O.htdemucs_forward(osd, seg, 4)
+        trim = (SL - n) // 2
+        err = (out[..., off + lo:off + hi].cpu().double() - want[..., trim + lo:trim + hi]).abs().max().item()
         assert err <= TOL, (k, err)

@@ -33,7 +33,8 @@ def fake_reference_modules(monkeypatch):
 def _package(klass, half):
     cfg = HTDemucsConfig()
     state = {k: torch.from_numpy(v).to(torch.half if half else torch.float32) for k, v in synthetic_state_dict(cfg, 7).items()}
-    return {"klass": klass, "args": (list(cfg.sources),), "kwargs": {"segment": Fraction(39, 5), "t_dropout": 0.0, "made_up_knob": 3},
+    return {"klass": klass, "args": (list(cfg.sources),), "kwargs": {"segment": Fraction(39, 5), "dconv_mode": 3, "bottom_channels": 512, "t_dropout": 0.0, "t_cross_first": False,
+                                                               "t_emb": "sin", "emb_smooth": True, "norm_starts": 4, "made_up_knob": 3},
             "state": state, "training_args": {"lr": 3e-4}}
 
 
@@ -59,7 +60,8 @@ def test_strict_rejects_unknown_keywords_and_dict_input_works(fake_reference_mod
     pkg = _package(fake_reference_modules["HTDemucs"], False)
     with pytest.raises(ValueError):
         states.load_model(dict(pkg), strict=True)
-    model = states.load_model({**pkg, "klass": "demucs.htdemucs.HTDemucs", "kwargs": {"segment": Fraction(39, 5)}}, strict=True)
+    model = states.load_model({**pkg, "klass": "demucs.htdemucs.HTDemucs", "kwargs": {"segment": Fraction(39, 5), "dconv_mode": 3,
+                                                                                      "bottom_channels": 512}}, strict=True)
     assert isinstance(model, HTDemucs)
 
 
@@ -110,3 +112,32 @@ def test_local_repo_reads_signatures_checksums_and_bags(tmp_path, fake_reference
     bad.write_bytes(bad.read_bytes()[:-1] + b"\\0")
     with pytest.raises(states.ModelLoadingError, match="Invalid checksum"):
         states.LocalRepo(tmp_path).get_model("f7e0c4bc")
+
+
+RELEASED = {"segment": Fraction(39, 5), "dconv_mode": 3, "bottom_channels": 512}
+
+
+@pytest.mark.parametrize("flag", [{"t_cross_first": True}, {"t_emb": "scaled"}, {"t_norm_first": False}, {"t_gelu": False},
+                                  {"t_sparse_self_attn": True}, {"use_train_segment": False}, {"norm_starts": 2}, {"cac": False},
+                                  {"multi_freqs": [0.5]}, {"freq_emb": 0.0}])
+def test_shape_preserving_architecture_flags_are_refused_not_dropped(fake_reference_modules, flag):
+    """None of these changes a tensor shape, so load_state_dict could not notice them: the loader must."""
+    pkg = _package(fake_reference_modules["HTDemucs"], False)
+    pkg["kwargs"] = {**RELEASED, **flag}
+    with pytest.raises(ValueError):
+        states.load_model(pkg)
+
+
+def test_known_reference_keywords_load_silently_and_omitted_ones_mean_reference_defaults(fake_reference_modules):
+    from demucs_amd.weights import ENGINE_FIXED, INERT_KEYWORDS
+    pkg = _package(fake_reference_modules["HTDemucs"], False)
+    pkg["kwargs"] = {**RELEASED, **ENGINE_FIXED, **{k: 0 for k in INERT_KEYWORDS}, "norm_starts": 4, "multi_freqs": []}
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")               # a real checkpoint (about 60 keywords) must not warn
+        model = states.load_model(pkg)
+    assert model.segment == Fraction(39, 5)
+    # a package that omits dconv_mode / bottom_channels / segment asks for the reference defaults (1 / 0 / 10): another
+    # architecture, refused instead of silently running the released one
+    pkg["kwargs"] = {}
+    with pytest.raises(ValueError):
+        states.load_model(pkg)
