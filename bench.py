@@ -1,20 +1,28 @@
 """Benchmark of the segmented htdemucs inference path on MI355X.
 
-    python bench.py [--gpus N --steps K --warmup W]
+    python bench.py [--gpus N --steps K --warmup W] [--dtype f32|bf16|f16]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
-A "step" = one `apply_model(shifts=0, split=True, overlap=0.25)` pass over a synthetic 44.1 kHz stereo
-track that is already resident in HBM; the separated stems stay in HBM.  Per GPU the workload is
-BASELINE.json configs[1]: htdemucs 4-stem, fp32, a 3-minute track (31 segments of 7.8 s).  For N > 1
-the track is N x 3 minutes (weak scaling): segments are sharded over the ranks and the slabs are
-exchanged with one RCCL all-gather (demucs_amd/distributed.py).  value = audio-seconds / wall-seconds
-(whole job).  Rank 0 prints ONE JSON line with `roofline` (dominant kernel, HIP-event timed on the
-launch stream inside the timed region) and, at N = 1, `cpu_baseline` (the CPU oracle, i.e. a port of
-the reference `-d cpu` path, on a bounded sample of the same workload).
+A "step" = one `apply_model(shifts=0, split=True, overlap=0.25)` pass over a synthetic 44.1 kHz stereo track.
+
+N = 1   BASELINE.json configs[1]: htdemucs 4-stem, a 3-minute track (31 segments of 7.8 s).  `value` is measured with the
+        mix already resident in HBM and the stems left in HBM (the bench contract).  The same run also reports
+          * `host_to_host` -- SURVEY.md 8(d)'s span: pinned host mix in, stems materialised on the host (H2D + D2H inside
+            the clock), median of the timed steps;
+          * `fixed_track`  -- the 60-minute track of configs[3] on this one GPU: the N = 1 point of the fixed-length curve;
+          * `cpu_baseline` -- the CPU oracle (a port of the reference `-d cpu` path on the same library primitives) on a
+            bounded sample of the same workload, on the host cores.
+N > 1   BASELINE.json configs[3]: ONE fixed 60-minute track (616 segments) at every N ("scaling": "strong"): every pass's
+        segments are sharded over the ranks, each rank keeps its window of the mix and its slab of the stems, ONE RCCL
+        all-gather of the slabs over xGMI per step (demucs_amd/distributed.py); every rank ends with the full result in
+        HBM.  value = 3600 audio-seconds / max-over-ranks wall-seconds.
+Rank 0 prints ONE JSON line with `roofline` for the kernel class with the largest summed duration (HIP-event timed on the
+launch stream inside the timed region).
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -24,31 +32,39 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense f32-in MFMA peak
-BF16_MFMA_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA peak (the 2:1-sparsity figure is not used)
+# MI355X_MICROARCH.md: dense MFMA peaks per input type (the 2:1-sparsity figures are never used), HBM3E
+MFMA_PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "f16": 2500.0}
 X6_PRODUCTS = 6                   # gemm_x6.hip: bf16 MFMA products issued per fp32 multiply-accumulate
 HBM_PEAK_GBPS = 8000.0
 SR = 44100
-TRACK_SECONDS_PER_GPU = 180
+TRACK_SECONDS = 180               # configs[1]
+FIXED_SECONDS = 3600              # configs[3]
+FLOP_PER_SEGMENT = 334.9e9
 
 
 def cpu_baseline(sd, sources, seconds=24):
-    """CPU oracle (port of the reference CPU path) timed on the host cores, float32, all threads."""
+    """CPU oracle (port of the reference CPU path, same library primitives) timed on the host cores, float32."""
     from demucs_amd.synth import synth_mix
     from oracle import apply_oracle as A
     from oracle import htdemucs_oracle as O
     torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))      # the GPU box gives one GPU a 16-core share
-    model = O.OracleModel(sd, sources)
-    length = seconds * SR
-    mix = torch.from_numpy(synth_mix(1, length, "noise"))[None]
-    A.apply_model(model, mix[..., :SR], shifts=0, split=True, overlap=0.25)      # warm-up forward
-    t0 = time.perf_counter()
-    A.apply_model(model, mix, shifts=0, split=True, overlap=0.25)
-    dt = time.perf_counter() - t0
+    O.FAST_PRIMITIVES = True      # th.stft / th.istft / fused attention, as the reference calls them
+    try:
+        model = O.OracleModel(sd, sources)
+        length = seconds * SR
+        mix = torch.from_numpy(synth_mix(1, length, "noise"))[None]
+        A.apply_model(model, mix[..., :SR], shifts=0, split=True, overlap=0.25)      # warm-up forward
+        t0 = time.perf_counter()
+        A.apply_model(model, mix, shifts=0, split=True, overlap=0.25)
+        dt = time.perf_counter() - t0
+    finally:
+        O.FAST_PRIMITIVES = False
     n_seg = len(range(0, length, int(0.75 * 343980)))
     return dict(value=round(seconds / dt, 3), unit="audio-sec/wall-sec", cores=torch.get_num_threads(), kind="port",
                 sample=f"{seconds} s of the same synthetic noise track ({n_seg} segment forwards), float32, "
-                       f"oracle.apply_oracle.apply_model, {dt:.1f} s wall")
+                       f"oracle.apply_oracle.apply_model on th.stft / th.istft / fused attention, {dt:.1f} s wall; in the build "
+                       "container (8 vCPU) this port ran at 0.98-1.28x the imported reference's own apply_model -d cpu "
+                       "(3 alternating runs, noisy host)")
 
 
 def main():
@@ -57,14 +73,15 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=32, help="segments per batched forward (workspace ~0.57 GB each)")
-    ap.add_argument("--seconds", type=int, default=TRACK_SECONDS_PER_GPU, help="track seconds per GPU")
+    ap.add_argument("--seconds", type=int, default=None, help="track seconds (default: 180 at N = 1, 3600 at N > 1)")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f16"], help="compute mode of the engine")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--pcie", action="store_true", help="also time host->device->host apply_model (reported separately)")
+    ap.add_argument("--no-host-leg", action="store_true")
+    ap.add_argument("--no-fixed-leg", action="store_true")
     args = ap.parse_args()
 
     import torch.distributed as dist
     from demucs_amd import apply as P
-    from demucs_amd.distributed import apply_model_sharded
     from demucs_amd.htdemucs import HTDemucs
     from demucs_amd.weights import HTDemucsConfig, synthetic_state_dict
 
@@ -83,36 +100,42 @@ def main():
 
     cfg = HTDemucsConfig()
     sd = synthetic_state_dict(cfg, 0)
-    model = HTDemucs(cfg.sources, max_batch=args.batch)
+    model = HTDemucs(cfg.sources, max_batch=args.batch, compute_dtype=args.dtype)
     model.load_state_dict(sd)
     model.to(dev).eval()
 
-    length = args.seconds * SR * world
-    gen = torch.Generator(device=dev).manual_seed(1)
-    mix = (torch.randn(1, 2, length, device=dev, generator=gen) * 0.1).contiguous()     # synthetic, resident in HBM
-    n_segments = len(range(0, length, int(0.75 * cfg.segment_length)))
+    seconds = args.seconds or (TRACK_SECONDS if world == 1 else FIXED_SECONDS)
+    stride = int(0.75 * cfg.segment_length)
 
-    def step():
-        if world > 1:
-            return apply_model_sharded(model, mix, overlap=0.25)
-        return P.apply_model(model, mix, shifts=0, split=True, overlap=0.25)
+    def make_mix(secs):
+        gen = torch.Generator(device=dev).manual_seed(1)                # same stream on every rank
+        return (torch.randn(1, 2, secs * SR, device=dev, generator=gen) * 0.1).contiguous()
+
+    def step(m):
+        # with a process group of more than one rank apply_model shards the segments by itself
+        return P.apply_model(model, m, shifts=0, split=True, overlap=0.25, device=dev)
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    mix = make_mix(seconds)                                             # synthetic, resident in HBM
+    length = mix.shape[-1]
+    n_segments = len(range(0, length, stride))
+    out = None
     for _ in range(args.warmup):
-        out = step()
+        out = step(mix)
     fence()
     model.profile_begin()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = step()
+        out = step(mix)
     fence()
     elapsed = time.perf_counter() - t0
     rows = model.profile_end()
-    assert out.shape == (1, 4, 2, length) and bool(torch.isfinite(out[0, 0, 0, ::997]).all())
+    assert out.shape == (1, 4, 2, length) and out.device == dev and bool(torch.isfinite(out[0, 0, 0, ::997]).all())
+    del out
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -123,33 +146,43 @@ def main():
         dom = max(rows, key=lambda r: r["ms"])
         dom_ms = dom["ms"] / dom["launches"]
         algo_tflops = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-        # conv_gemm_x6 classes run fp32 operands as 3 exact bf16 terms x 6 bf16 MFMA products: the matrix pipe is priced
-        # by the bf16 flops it actually issues (6 x algorithmic) against the dense bf16 peak
         x6 = dom["name"].startswith("conv_gemm_x6")
-        achieved = algo_tflops * (X6_PRODUCTS if x6 else 1)
-        peak = BF16_MFMA_PEAK_TFLOPS if x6 else FP32_MFMA_PEAK_TFLOPS
+        pipe = "bf16" if x6 else dom.get("pipe", args.dtype if args.dtype != "f32" else "f32")
+        if dom["name"].startswith("dconv") or dom["name"].startswith("stft") or dom["name"].startswith("istft"):
+            bound, achieved, peak, unit = "hbm", dom["bytes"] / (dom["ms"] * 1e-3) / 1e9, HBM_PEAK_GBPS, "GB/s"
+        else:
+            # conv_gemm_x6 classes run fp32 operands as 3 exact bf16 terms x 6 bf16 MFMA products: the matrix pipe is
+            # priced by the bf16 flops it actually issues (6 x algorithmic) against the dense bf16 peak
+            bound, achieved, peak, unit = "mfma", algo_tflops * (X6_PRODUCTS if x6 else 1), MFMA_PEAK_TFLOPS[pipe], "TFLOP/s"
         total_ms = sum(r["ms"] for r in rows)
         traffic, traffic_src = None, None        # HBM bytes per launch from the committed PMC passes of this same command
-        tpath = os.path.join(ROOT, "profiles", "round1_traffic.json")
-        if os.path.exists(tpath) and world == 1 and args.batch == 32 and args.seconds == TRACK_SECONDS_PER_GPU:
-            entry = json.load(open(tpath)).get(dom["name"])
-            if entry:
-                traffic, traffic_src = entry["traffic_bytes_per_launch"], "profiles/round1_traffic.json: " + entry["method"]
+        for tname in ("round2_traffic.json", "round1_traffic.json"):
+            tpath = os.path.join(ROOT, "profiles", tname)
+            if traffic is None and os.path.exists(tpath) and world == 1 and args.batch == 32 and seconds == TRACK_SECONDS:
+                entry = json.load(open(tpath)).get(dom["name"] + ("" if args.dtype == "f32" else "@" + args.dtype))
+                if entry:
+                    traffic = entry["traffic_bytes_per_launch"]
+                    traffic_src = f"profiles/{tname} (separate rocprofv3 --pmc passes of this command, replayed here): " + entry["method"]
+        dtype_words = {"f32": "fp32 (fp32 MFMA, exact)", "bf16": "bf16 MFMA operands, fp32 accumulate / statistics / softmax / iSTFT",
+                       "f16": "fp16 MFMA operands, fp32 accumulate / statistics / softmax / iSTFT"}[args.dtype]
         result = {
-            "metric": "real-time factor (audio-sec/wall-sec) htdemucs 4-stem 44.1kHz stereo",
+            "metric": "real-time factor (audio-sec/wall-sec) htdemucs 4-stem 44.1kHz stereo, 1/8 GPU",
             "value": round(length / SR / sec_per_step, 2), "unit": "audio-sec/wall-sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(sec_per_step * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"htdemucs 4-stem fp32, {args.seconds * world // 60}-min synthetic 44.1 kHz stereo track "
-                                   f"resident in HBM ({args.seconds} s per GPU), segment=7.8 s overlap=0.25 shifts=0, "
-                                   f"{n_segments} segments, {args.batch} segments per batched forward, random-init weights "
-                                   "(synthetic_state_dict seed 0), stems left in HBM",
-                       "parallelism": f"segments sharded over {world} GPU(s)" + (", one RCCL all-gather of slabs" if world > 1 else "")},
-            "roofline": {"bound": "mfma", "kernel": dom["name"], "achieved": round(achieved, 2), "peak": peak,
-                         "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
+            "higher_is_better": True, "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": (f"BASELINE configs[{1 if seconds == TRACK_SECONDS else 3}]: htdemucs 4-stem, {dtype_words}, "
+                                    f"{seconds // 60}-min synthetic 44.1 kHz stereo track resident in HBM when the clock starts, stems "
+                                    f"left in HBM, segment=7.8 s overlap=0.25 shifts=0, {n_segments} segments, {args.batch} segments "
+                                    "per batched forward, random-init weights (synthetic_state_dict seed 0)"
+                                    + ("; the SAME fixed track at every N > 1 (strong scaling); N = 1 of that curve is "
+                                       "`fixed_track` in the N = 1 line" if world > 1 else "")),
+                       "parallelism": (f"segments sharded over {world} GPUs by track interval, one RCCL all-gather of stem slabs per step"
+                                       if world > 1 else "one GPU")},
+            "roofline": {"bound": bound, "kernel": dom["name"], "achieved": round(achieved, 2), "peak": peak,
+                         "unit": unit, "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "pipe": ("bf16 MFMA, 6 products per fp32 MAC (exact 3-term operand split, fp32 accumulate)" if x6
-                                  else "fp32 MFMA"),
-                         "fp32_equivalent_tflops": round(algo_tflops, 2),
+                                  else f"{pipe} MFMA" if bound == "mfma" else "HBM"),
                          "algorithmic_bytes_per_launch": round(dom["bytes"] / dom["launches"]),
                          "algorithmic_flops_per_launch": round(dom["flops"] / dom["launches"]),
                          "launches": dom["launches"], "avg_launch_ms": round(dom_ms, 4),
@@ -157,14 +190,41 @@ def main():
             "kernels": [{"name": r["name"], "launches": r["launches"], "ms": round(r["ms"], 3),
                          "tflops": round(r["flops"] / (r["ms"] * 1e-3) / 1e12, 2),
                          "gbps": round(r["bytes"] / (r["ms"] * 1e-3) / 1e9, 1)} for r in sorted(rows, key=lambda r: -r["ms"])],
-            "whole_path_tflops": round(334.9e9 * n_segments / world / sec_per_step / 1e12 * world, 2),
+            "whole_path_tflops": round(FLOP_PER_SEGMENT * n_segments / sec_per_step / 1e12, 2),
         }
-        if args.pcie and world == 1:
-            host_mix = mix.cpu().pin_memory()
-            P.apply_model(model, host_mix, shifts=0, device=dev)
+        if world == 1 and not args.no_host_leg:
+            # apply_model entry with the mix on the host -> stems materialised on the host
+            host_mix = torch.empty(mix.shape, dtype=torch.float32, pin_memory=True)
+            host_mix.copy_(mix)
+            torch.cuda.synchronize(dev)
+            step(host_mix)
+            times = []
+            for _ in range(max(3, min(args.steps, 7))):
+                t1 = time.perf_counter()
+                host_out = step(host_mix)
+                times.append(time.perf_counter() - t1)
+            assert host_out.device.type == "cpu" and host_out.shape == (1, 4, 2, length)
+            med = statistics.median(times)
+            result["host_to_host"] = {"value": round(length / SR / med, 2), "unit": "audio-sec/wall-sec", "ms_per_step": round(med * 1e3, 3),
+                                      "runs": len(times), "span": "apply_model entry with a pinned host mix (63.5 MB H2D) -> the 254 MB of "
+                                      "stems in a pinned host tensor (D2H), SURVEY.md 8(d); median"}
+            del host_out, host_mix
+        if world == 1 and not args.no_fixed_leg and seconds != FIXED_SECONDS:
+            del mix
+            torch.cuda.empty_cache()
+            long_mix = make_mix(FIXED_SECONDS)
+            step(long_mix)
+            torch.cuda.synchronize(dev)
             t1 = time.perf_counter()
-            P.apply_model(model, host_mix, shifts=0, device=dev)
-            result["pcie_inclusive_value"] = round(length / SR / (time.perf_counter() - t1), 2)
+            o = step(long_mix)
+            torch.cuda.synchronize(dev)
+            dt = time.perf_counter() - t1
+            assert bool(torch.isfinite(o[0, 0, 0, ::99991]).all())
+            result["fixed_track"] = {"seconds": FIXED_SECONDS, "segments": len(range(0, FIXED_SECONDS * SR, stride)),
+                                     "value": round(FIXED_SECONDS / dt, 2), "unit": "audio-sec/wall-sec", "ms_per_step": round(dt * 1e3, 2),
+                                     "note": "configs[3]'s 60-minute track on ONE GPU, HBM-resident like `value`: the N = 1 point of the "
+                                             "fixed-length (strong-scaling) curve that `--gpus N > 1` continues"}
+            del o, long_mix
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(sd, cfg.sources)
         print(json.dumps(result), flush=True)

@@ -21,7 +21,7 @@ class MiTensorDesc(C.Structure):
 
 class MiConfig(C.Structure):
     _fields_ = [("n_sources", C.c_int32), ("segment_length", C.c_int32), ("max_batch", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("dtype", C.c_int32)]
 
 
 class MiProfileRow(C.Structure):
@@ -53,7 +53,7 @@ SIGNATURES = {
     "mi_model_create": (C.c_int, [C.POINTER(MiConfig), C.POINTER(MiTensorDesc), C.c_size_t, C.POINTER(C.c_void_p)]),
     "mi_model_destroy": (None, [C.c_void_p]),
     "mi_model_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
-    "mi_model_forward_core": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "mi_model_forward_core": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "mi_model_tap": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.c_void_p]),
     "mi_profile_begin": (C.c_int, [C.c_void_p]),
     "mi_profile_end": (C.c_int, [C.c_void_p, C.POINTER(MiProfileRow), C.c_int32, C.POINTER(C.c_int32), C.c_void_p]),

@@ -105,9 +105,10 @@ int mi_model_tap(void *handle, const char *name, float *dst_dev, int32_t B, int6
     return MI_OK;
 }
 
-int mi_model_forward_core(void *handle, const float *mix_dev, float *spec_out_dev, float *time_out_dev, int32_t B, void *stream) {
+int mi_model_forward_core(void *handle, const float *mix_dev, const float *mag_dev, float *spec_out_dev, float *time_out_dev,
+                          int32_t B, void *stream) {
     if (!handle) return set_error(MI_EINVAL, "mi_model_forward_core: null handle");
-    return ((Model *)handle)->forward_core(mix_dev, spec_out_dev, time_out_dev, B, (hipStream_t)stream);
+    return ((Model *)handle)->forward_core(mix_dev, mag_dev, spec_out_dev, time_out_dev, B, (hipStream_t)stream);
 }
 
 int mi_profile_begin(void *handle) {

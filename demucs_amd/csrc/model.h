@@ -123,9 +123,9 @@ struct Model : WorkspacePtrs {
     ~Model();
     int init(const mi_config &c, const mi_tensor_desc *weights, size_t n);
     int forward(const float *mix, float *out, int B, hipStream_t st);
-    int forward_core(const float *mix, float *spec_out, float *time_out, int B, hipStream_t st);
-    int run_core(const float *mix, int B, hipStream_t st);
-    int run_core_impl(const float *mix, int B, hipStream_t st);
+    int forward_core(const float *mix, const float *mag, float *spec_out, float *time_out, int B, hipStream_t st);
+    int run_core(const float *mix, const float *mag, int B, hipStream_t st);
+    int run_core_impl(const float *mix, const float *mag, int B, hipStream_t st);
 
    private:
     int dev_alloc(void **p, size_t bytes);

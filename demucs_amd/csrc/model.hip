@@ -305,6 +305,7 @@ int Model::init(const mi_config &c, const mi_tensor_desc *weights, size_t n) {
     cfg = c;
     MI_REQUIRE(c.n_sources >= 1 && c.n_sources <= 8, "n_sources %d unsupported", c.n_sources);
     MI_REQUIRE(c.max_batch >= 1 && c.max_batch <= 64, "max_batch %d out of range [1, 64]", c.max_batch);
+    MI_REQUIRE(c.dtype == MI_DTYPE_F32, "compute dtype %d not available in this build", c.dtype);
     MI_REQUIRE(c.segment_length > 4096 && c.segment_length % 4 == 0, "segment_length %d unsupported", c.segment_length);
     S = c.n_sources; SL = c.segment_length; T = (SL + 1023) / 1024;
     MI_REQUIRE(T % 4 == 0, "segment_length %d gives %d STFT frames; the engine needs a multiple of 4", SL, T);
@@ -712,20 +713,20 @@ int Model::run_tr_layer(int br, int k, int B, const float *x, const float2 *xsta
 // forward
 // ------------------------------------------------------------------------------------------------
 // run_core with the "statistics slots may be dirty" bookkeeping of the (possibly shared) workspace
-int Model::run_core(const float *mix, int B, hipStream_t st) {
+int Model::run_core(const float *mix, const float *mag, int B, hipStream_t st) {
     if (ws->dirty) {
         MI_HIP(hipMemsetAsync(w_stats, 0, ws->stats_bytes, st));
         MI_HIP(hipMemsetAsync(w_stats_t, 0, ws->stats_bytes, st));
         ws->dirty = false;
     }
-    const int r = run_core_impl(mix, B, st);
+    const int r = run_core_impl(mix, mag, B, st);
     if (r != MI_OK) ws->dirty = true;
     return r;
 }
 
 int Model::forward(const float *mix, float *out, int B, hipStream_t st) {
     MI_REQUIRE(mix && out, "forward: null buffer");
-    MI_TRY(run_core(mix, B, st));
+    MI_TRY(run_core(mix, nullptr, B, st));
     // ---- de-normalise, iSTFT, add the time branch (htdemucs.py:624-657) -----------------------------
     MI_TRY(launch_istft(w_yspec, B, S, SL, w_denorm_f, w_ytime, w_denorm_t, fft, w_yt, w_fr, out, st));
     MI_STAGE("istft done");
@@ -734,16 +735,16 @@ int Model::forward(const float *mix, float *out, int B, hipStream_t st) {
 
 // HTDemucs.forward_core (htdemucs.py:662-759): the network without iSTFT / branch sum.
 // spec_out (B, S, 4, 2048, T) = decoder output * std + mean; time_out (B, S, 2, L) = time decoder * stdt + meant.
-int Model::forward_core(const float *mix, float *spec_out, float *time_out, int B, hipStream_t st) {
+int Model::forward_core(const float *mix, const float *mag, float *spec_out, float *time_out, int B, hipStream_t st) {
     MI_REQUIRE(mix && spec_out && time_out, "forward_core: null buffer");
-    MI_TRY(run_core(mix, B, st));
+    MI_TRY(run_core(mix, mag, B, st));
     MI_TRY(launch_row_denorm(w_yspec, B, (int64_t)4 * S * 2048 * T, w_denorm_f, spec_out, st));
     MI_TRY(launch_row_denorm(w_ytime, B, (int64_t)2 * S * SL, w_denorm_t, time_out, st));
     return MI_OK;
 }
 
 // everything up to the decoder outputs: leaves w_yspec / w_ytime and the (mean, std) pairs in the workspace
-int Model::run_core_impl(const float *mix, int B, hipStream_t st) {
+int Model::run_core_impl(const float *mix, const float *mag, int B, hipStream_t st) {
     MI_REQUIRE(B >= 1 && B <= cfg.max_batch, "forward: batch %d outside [1, %d]", B, cfg.max_batch);
     const int Tf = 8 * T, Tt = Lt[4];
     // ---- input statistics and normalisation (htdemucs.py:545-554) --------------------------------
@@ -751,9 +752,16 @@ int Model::run_core_impl(const float *mix, int B, hipStream_t st) {
     MI_TRY(launch_finalize_stats(w_stats_t, B, 2.0 * SL, 1e-5f, 1, w_norm_t, w_denorm_t, st));
     MI_TRY(launch_row_affine(mix, B, (int64_t)2 * SL, w_norm_t, w_xt0, st));
     MI_STAGE("time normalisation done");
-    MI_TRY(launch_stft_frames(mix, B, SL, fft, w_zt, w_stats, st));
-    MI_TRY(launch_finalize_stats(w_stats, B, 4.0 * 2048 * T, 1e-5f, 1, w_norm_f, w_denorm_f, st));
-    MI_TRY(launch_cac_transpose(w_zt, B, T, w_norm_f, w_x0, st));
+    if (mag) {      // forward_core with a caller-computed spectrogram (htdemucs.py:662-690: `mag` is an INPUT there)
+        const int64_t cnt = (int64_t)4 * 2048 * T;
+        MI_TRY(launch_row_stats(mag, B, cnt, cnt, w_stats, st));
+        MI_TRY(launch_finalize_stats(w_stats, B, (double)cnt, 1e-5f, 1, w_norm_f, w_denorm_f, st));
+        MI_TRY(launch_row_affine(mag, B, cnt, w_norm_f, w_x0, st));
+    } else {
+        MI_TRY(launch_stft_frames(mix, B, SL, fft, w_zt, w_stats, st));
+        MI_TRY(launch_finalize_stats(w_stats, B, 4.0 * 2048 * T, 1e-5f, 1, w_norm_f, w_denorm_f, st));
+        MI_TRY(launch_cac_transpose(w_zt, B, T, w_norm_f, w_x0, st));
+    }
     MI_STAGE("stft done");
 
     // ---- encoders ----------------------------------------------------------------------------------

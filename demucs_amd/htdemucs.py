@@ -27,7 +27,11 @@ __all__ = ["HTDemucs"]
 
 
 class HTDemucs:
-    def __init__(self, sources: List[str], segment=Fraction(39, 5), max_batch: int = 8, **kwargs):
+    #: compute modes of the engine (mi_config.dtype): operand type of the matrix-core GEMMs and of attention;
+    #: accumulation, statistics, norms, softmax and the STFT / iSTFT are float32 in every mode
+    COMPUTE_DTYPES = {"f32": 0, "bf16": 1, "f16": 2}
+
+    def __init__(self, sources: List[str], segment=Fraction(39, 5), max_batch: int = 8, compute_dtype: str = "f32", **kwargs):
         cfg = HTDemucsConfig(sources=list(sources), segment=Fraction(segment) if not isinstance(segment, Fraction) else segment)
         for k, v in kwargs.items():            # accept the reference's keyword names, reject other architectures
             if hasattr(cfg, k):
@@ -42,6 +46,9 @@ class HTDemucs:
         self.segment = cfg.segment
         self.use_train_segment = True
         self.max_batch = int(max_batch)
+        if compute_dtype not in self.COMPUTE_DTYPES:
+            raise ValueError(f"compute_dtype must be one of {sorted(self.COMPUTE_DTYPES)}, got {compute_dtype!r}")
+        self.compute_dtype = compute_dtype
         self._schema = htdemucs_schema(cfg)
         self._state: Optional["OrderedDict[str, np.ndarray]"] = None
         self._handles: Dict[torch.device, int] = {}      # engine handle per GPU the model has been used on
@@ -143,12 +150,19 @@ class HTDemucs:
             descs[i].name = k.encode()
             descs[i].data = v.ctypes.data
             descs[i].numel = v.size
-        cfg = _lib.MiConfig(len(self.sources), self.segment_length, self.max_batch, 0)
+        cfg = _lib.MiConfig(len(self.sources), self.segment_length, self.max_batch, self.COMPUTE_DTYPES[self.compute_dtype])
         h = C.c_void_p()
         with torch.cuda.device(self._device):
             _lib.check(lib.mi_model_create(C.byref(cfg), descs, len(names), C.byref(h)), "mi_model_create")
         self._handles[self._device] = h.value
         return h.value
+
+    def set_compute_dtype(self, compute_dtype: str):
+        if compute_dtype not in self.COMPUTE_DTYPES:
+            raise ValueError(f"compute_dtype must be one of {sorted(self.COMPUTE_DTYPES)}, got {compute_dtype!r}")
+        if compute_dtype != self.compute_dtype:
+            self.compute_dtype = compute_dtype
+            self._release()
 
     def set_max_batch(self, max_batch: int):
         if max_batch != self.max_batch:
@@ -207,15 +221,21 @@ class HTDemucs:
 
     def forward_core(self, mag: Optional[torch.Tensor], mix: torch.Tensor):
         """HTDemucs.forward_core (htdemucs.py:662-759): (spec_out (B,S,4,2048,T), time_out (B,S,2,L)).
-        `mag` must be `_magnitude(_spec(mix))` by the reference's contract; the engine recomputes it from
-        `mix`, so it may be None (a given `mag` is only shape-checked)."""
+        `mag` (B,4,2048,T) is the caller's `_magnitude(_spec(mix))` and feeds the frequency branch as given (the
+        fork's ONNX / web tools compute it with their own STFT); None = the engine's own STFT of `mix`."""
         SL = self.segment_length
         if mix.dim() != 3 or mix.shape[1] != self.audio_channels or mix.shape[2] != SL or mix.dtype != torch.float32:
             raise ValueError(f"expected float32 (B, {self.audio_channels}, {SL}), got {tuple(mix.shape)} {mix.dtype}")
         B, S, T = mix.shape[0], len(self.sources), -(-SL // 1024)
-        if mag is not None and tuple(mag.shape) != (B, 4, 2048, T):
-            raise ValueError(f"mag must be (B, 4, 2048, {T}), got {tuple(mag.shape)}")
+        if mag is not None:
+            if tuple(mag.shape) != (B, 4, 2048, T) or mag.dtype != torch.float32:
+                raise ValueError(f"mag must be float32 (B, 4, 2048, {T}), got {tuple(mag.shape)} {mag.dtype}")
+            if mag.device != mix.device:
+                raise ValueError("mag and mix must live on the same device")
+            mag = mag.contiguous()
         handle = self._ensure_handle()
+        if mix.device != self._device:
+            raise _lib.EngineError(f"mix is on {mix.device} but the model is on {self._device}")
         mix = mix.contiguous()
         spec = torch.empty(B, S, 4, 2048, T, device=mix.device, dtype=torch.float32)
         tout = torch.empty(B, S, self.audio_channels, SL, device=mix.device, dtype=torch.float32)
@@ -223,9 +243,10 @@ class HTDemucs:
         with torch.cuda.device(self._device):
             for b0 in range(0, B, self.max_batch):
                 nb = min(self.max_batch, B - b0)
-                _lib.check(lib.mi_model_forward_core(C.c_void_p(handle), mix[b0:b0 + nb].data_ptr(), spec[b0:b0 + nb].data_ptr(),
-                                                     tout[b0:b0 + nb].data_ptr(), nb, C.c_void_p(_lib.current_stream_ptr())),
-                           "mi_model_forward_core")
+                _lib.check(lib.mi_model_forward_core(C.c_void_p(handle), mix[b0:b0 + nb].data_ptr(),
+                                                     mag[b0:b0 + nb].data_ptr() if mag is not None else None,
+                                                     spec[b0:b0 + nb].data_ptr(), tout[b0:b0 + nb].data_ptr(), nb,
+                                                     C.c_void_p(_lib.current_stream_ptr())), "mi_model_forward_core")
         return spec, tout
 
     def __call__(self, mix: torch.Tensor) -> torch.Tensor:

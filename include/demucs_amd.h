@@ -47,8 +47,16 @@ typedef struct mi_config {
     int32_t n_sources;       /* len(model.sources): 4 (htdemucs, htdemucs_ft) or 6 (htdemucs_6s) */
     int32_t segment_length;  /* int(model.segment * model.samplerate) = 343980                   */
     int32_t max_batch;       /* segments per forward the workspace is sized for                  */
-    int32_t reserved;
+    int32_t dtype;           /* MI_DTYPE_*: operand type of the matrix-core GEMMs and attention  */
 } mi_config;
+
+/* Compute modes.  F32 is the parity mode (fp32 MFMA, exact fp32 arithmetic, <= 1e-4 of the CPU reference).
+ * BF16 / F16 round the OPERANDS of every conv / linear GEMM and of the attention products to bf16 / fp16 and
+ * feed them to v_mfma_f32_32x32x16_{bf16,f16}; accumulation, biases, GroupNorm / LayerNorm statistics, softmax,
+ * GELU / GLU, the STFT / iSTFT and all activations in HBM stay float32 (BASELINE.json configs[2], configs[4]). */
+#define MI_DTYPE_F32 0
+#define MI_DTYPE_BF16 1
+#define MI_DTYPE_F16 2
 
 /* ---- model lifetime: replaces `states.load_model` + `model.to(device)`
  *      (demucs/states.py:50-80, demucs/apply.py:233) ------------------------------------- */
@@ -61,11 +69,12 @@ void mi_model_destroy(void *handle);
 int mi_model_forward(void *handle, const float *mix_dev, float *out_dev, int32_t B, void *stream);
 
 /* ---- `HTDemucs.forward_core(mag, mix)` (demucs/htdemucs.py:662-759; the fork's ONNX "core", docs/onnx.md):
- *      the network without the iSTFT and the branch sum.  `mag` is by contract `_magnitude(_spec(mix))`, which the
- *      engine derives from mix_dev (B, 2, segment_length) itself.  spec_out_dev: (B, S, 4, 2048, T);
- *      time_out_dev: (B, S, 2, segment_length). -------------------------------------------------------- */
-int mi_model_forward_core(void *handle, const float *mix_dev, float *spec_out_dev, float *time_out_dev, int32_t B,
-                          void *stream);
+ *      the network without the STFT in front, the iSTFT behind and the branch sum.  mag_dev (B, 4, 2048, T) is the
+ *      caller's `_magnitude(_spec(mix))` (the fork's ONNX / web tools compute it with their own STFT) and is what
+ *      the frequency branch consumes; NULL = derive it from mix_dev (B, 2, segment_length) with the engine's STFT.
+ *      spec_out_dev: (B, S, 4, 2048, T); time_out_dev: (B, S, 2, segment_length). --------------------------- */
+int mi_model_forward_core(void *handle, const float *mix_dev, const float *mag_dev, float *spec_out_dev,
+                          float *time_out_dev, int32_t B, void *stream);
 
 /* Debug / parity aid: copy an internal activation left behind by the last mi_model_forward
  * (first B items) into dst_dev (may be NULL to query *numel_per_item only).  Names: "x0" (normalised CaC spectrogram),

@@ -154,3 +154,20 @@ def new_sdr(references: Tensor, estimates: Tensor) -> Tensor:
     num = torch.sum(torch.square(references), dim=(2, 3)) + delta
     den = torch.sum(torch.square(references - estimates), dim=(2, 3)) + delta
     return 10 * torch.log10(num / den)
+
+
+def separate_tensor(model, wav: Tensor, callback=None, callback_arg=None, **params):
+    """Separator.separate_tensor at the model's own sample rate (demucs/api.py:265-291): `wav` (channels, length) is
+    normalised IN PLACE by the mean / unbiased std of its mono mix-down (+1e-8), separated with `apply_model`, the stems
+    and `wav` itself are mapped back; returns (wav, {source: stem})."""
+    ref = wav.mean(0)
+    wav -= ref.mean()
+    wav /= ref.std() + 1e-8
+    arg = dict(callback_arg or {})
+    arg["audio_length"] = wav.shape[1]                                   # api.py:281-283
+    out = apply_model(model, wav[None], callback=callback, callback_arg=arg, **params)
+    out *= ref.std() + 1e-8
+    out += ref.mean()
+    wav *= ref.std() + 1e-8
+    wav += ref.mean()
+    return wav, dict(zip(model.sources, out[0]))

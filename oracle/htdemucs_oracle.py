@@ -27,6 +27,12 @@ Tensor = torch.Tensor
 NFFT = 4096
 HOP = 1024
 
+# bench.py's cpu_baseline leg sets this: the SAME library primitives the reference calls (th.stft / th.istft,
+# spec.py:17-25,38-45; the fused attention inside nn.MultiheadAttention, transformer.py:418-419,506) instead of the
+# from-definition restatements below, so that the timed CPU port runs at the reference's speed.  Parity tests keep
+# it False: the restatements are the independent check.
+FAST_PRIMITIVES = False
+
 
 # --------------------------------------------------------------------------------------
 # DSP (reference: demucs/spec.py:11-47, demucs/htdemucs.py:420-450, demucs/hdemucs.py:23-40)
@@ -62,6 +68,11 @@ def stft_cac(mix: Tensor) -> Tensor:
     le = int(math.ceil(L / HOP))
     pad = HOP // 2 * 3
     x = reflect_pad(mix, pad, pad + le * HOP - L)              # htdemucs.py:433-435
+    if FAST_PRIMITIVES:
+        z = torch.stft(x.reshape(-1, x.shape[-1]), NFFT, HOP, window=hann_periodic(NFFT, mix.dtype), win_length=NFFT,
+                       normalized=True, center=True, return_complex=True, pad_mode="reflect")
+        z = z.view(B, C, NFFT // 2 + 1, -1)[..., :-1, 2:2 + le]
+        return torch.view_as_real(z).permute(0, 1, 4, 2, 3).reshape(B, C * 2, NFFT // 2, le)
     x = reflect_pad(x, NFFT // 2, NFFT // 2)                    # th.stft(center=True, reflect)
     frames = x.unfold(-1, NFFT, HOP)                            # (B,C,le+4,4096)
     assert frames.shape[-2] == le + 4
@@ -84,6 +95,10 @@ def istft_from_cac(x: Tensor, length: int) -> Tensor:
     le = HOP * int(math.ceil(length / HOP)) + 2 * pad
     n_frames = T + 4
     w = hann_periodic(NFFT, x.dtype)
+    if FAST_PRIMITIVES:
+        y = torch.istft(z.reshape(-1, Fr + 1, n_frames), NFFT, HOP, window=w, win_length=NFFT, normalized=True, length=le,
+                        center=True)
+        return y.view(B, S, C2 // 2, le)[..., pad:pad + length]
     fr = torch.fft.irfft(z.transpose(-1, -2) * math.sqrt(NFFT), n=NFFT, dim=-1) * w   # (B,S,C,T+4,4096)
     total = NFFT + HOP * (n_frames - 1)
     y = torch.zeros(B, S, C2 // 2, total, dtype=x.dtype)
@@ -210,8 +225,11 @@ def mha(sd, p: str, q: Tensor, k: Tensor, heads: int = 8) -> Tensor:
     Q = F.linear(q, W[:D], b[:D]).view(B, Tq, heads, D // heads).transpose(1, 2)
     K = F.linear(k, W[D:2 * D], b[D:2 * D]).view(B, Tk, heads, D // heads).transpose(1, 2)
     V = F.linear(k, W[2 * D:], b[2 * D:]).view(B, Tk, heads, D // heads).transpose(1, 2)
-    att = torch.softmax(Q @ K.transpose(-1, -2) / math.sqrt(D // heads), dim=-1)
-    o = (att @ V).transpose(1, 2).reshape(B, Tq, D)
+    if FAST_PRIMITIVES:
+        o = F.scaled_dot_product_attention(Q, K, V).transpose(1, 2).reshape(B, Tq, D)
+    else:
+        att = torch.softmax(Q @ K.transpose(-1, -2) / math.sqrt(D // heads), dim=-1)
+        o = (att @ V).transpose(1, 2).reshape(B, Tq, D)
     return F.linear(o, sd[f"{p}.out_proj.weight"], sd[f"{p}.out_proj.bias"])
 
 
@@ -273,7 +291,7 @@ def cross_transformer(sd, x: Tensor, xt: Tensor, taps=None):
 # Whole model (reference: demucs/htdemucs.py:527-660)
 # --------------------------------------------------------------------------------------
 def htdemucs_forward(sd: Dict[str, Tensor], mix: Tensor, n_sources: int = 4, segment_length: int = 343980,
-                     taps: Optional[dict] = None) -> Tensor:
+                     taps: Optional[dict] = None, mag_override: Optional[Tensor] = None) -> Tensor:
     """mix (B,2,n<=segment_length) -> (B,S,2,n).  `sd` tensors must have mix's dtype."""
     length = mix.shape[-1]
     length_pre_pad = None
@@ -284,7 +302,8 @@ def htdemucs_forward(sd: Dict[str, Tensor], mix: Tensor, n_sources: int = 4, seg
         raise ValueError(f"Given length {length} is longer than training length {segment_length}")
     B = mix.shape[0]
     S = n_sources
-    mag = stft_cac(mix)
+    # forward_core (htdemucs.py:662-690) takes `mag` as an input: mag_override stands for a caller-computed one
+    mag = stft_cac(mix) if mag_override is None else mag_override.to(mix.dtype)
     if taps is not None: taps["stft"] = mag
     mean = mag.mean(dim=(1, 2, 3), keepdim=True)
     std = mag.std(dim=(1, 2, 3), keepdim=True)                     # unbiased (:546)

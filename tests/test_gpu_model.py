@@ -54,9 +54,14 @@ def test_forward_matches_reference_golden(golden, name):
     names = {"dec3": "yspec", "tdec3": "ytime"}
     worst = {}
     for tap, shape in shapes.items():
-        if tap == "enc0":
-            continue            # the golden hook sees encoder.0 before the frequency embedding is added
         t = model.tap(names.get(tap, tap), 1)
+        if tap == "enc0":
+            # the golden hook sees encoder.0 BEFORE the frequency embedding is added (htdemucs.py:577-582): take the
+            # embedding 0.2 * (10 * weight).t() off the engine's tap and compare with `enc0_preemb`
+            w = torch.from_numpy(synthetic_state_dict(cfg, wseed)["freq_emb.embedding.weight"]).cuda()      # (512, 48)
+            t = t.reshape(shape) - (0.2 * (w * 10.0)).t()[None, :, :, None]
+            worst[tap] = g.check("f64", "enc0_preemb", t, atol=2e-4, rtol=2e-4)
+            continue
         if tap.startswith("tenc"):                           # time-branch rows carry a pitch rounded up to 4
             t = t.view(1, shape[1], -1)[..., :shape[2]]
         t = t.reshape(shape)
@@ -111,6 +116,18 @@ def test_forward_core_contract():
     assert (wav + tout - full).abs().max().item() < 2e-5
     with pytest.raises(ValueError):
         model.forward_core(torch.zeros(1, 4, 2048, 10), mix.cuda())
+    # a caller-supplied `mag` is what the frequency branch consumes (the fork's ONNX / web tools compute it with their
+    # own STFT): the oracle's spectrogram reproduces the mag=None result, a different spectrogram changes spec_out only
+    mag = taps["stft"].float().cuda()
+    spec2, tout2 = model.forward_core(mag, mix.cuda())
+    assert (spec2 - spec).abs().max().item() <= 2e-4 * spec.abs().max().item()
+    assert (tout2 - tout).abs().max().item() <= 2e-4 * tout.abs().max().item()
+    spec3, _ = model.forward_core(0.5 * mag + 0.01, mix.cuda())
+    taps3 = {}
+    with torch.no_grad():
+        O.htdemucs_forward(O.to_torch_state(sd, torch.float64), mix.double(), 4, taps=taps3, mag_override=0.5 * taps["stft"] + 0.01)
+    assert (spec3.cpu().double() - taps3["spec_out"]).abs().max().item() <= 2e-4 * taps3["spec_out"].abs().max().item()
+    assert (spec3 - spec).abs().max().item() > 1e-3
 
 
 def test_model_rejects_cpu_and_bad_shapes():

@@ -111,3 +111,29 @@ def test_center_trim_and_errors():
         A.apply_model(m, torch.zeros(1, 2, SL + 5), shifts=0, split=False)
     with pytest.raises(AssertionError):                                # apply.py:235
         A.apply_model(m, torch.zeros(1, 2, 1000), shifts=0, transition_power=0.5)
+
+
+def separator_input():
+    return 3.0 * synth_mix(12, int(1.3 * SL), "tones") + 0.2
+
+
+def test_separate_tensor_matches_reference_separator(golden):
+    """tests/golden/separator_shift1.npz = the reference's own `Separator.separate_tensor` (api.py:241-291) run by
+    tools/make_golden.py; checks the normalise / separate / restore contract and the callback dicts (audio_length)."""
+    g = golden("separator_shift1")
+    cfg = HTDemucsConfig()
+    model = O.OracleModel(synthetic_state_dict(cfg, int(g.meta("wseed"))), cfg.sources)
+    wav = torch.from_numpy(separator_input())
+    wav0 = wav.clone()
+    events = []
+    random.seed(int(g.meta("rseed")))
+    got_wav, stems = A.separate_tensor(model, wav, callback=lambda d: events.append(dict(d)), callback_arg={"tag": "fixture"},
+                                       shifts=int(g.meta("kw_shifts")), overlap=float(g.meta("kw_overlap")), split=bool(g.meta("kw_split")))
+    assert got_wav is wav and float((wav - wav0).abs().max()) <= 4 * float(g.z["f32/restore_err"]) + 1e-6
+    assert list(stems) == cfg.sources
+    out = torch.stack([stems[k] for k in cfg.sources])
+    g.check("f32", "out", out, atol=2e-4, rtol=6e-5)              # outputs are ~3x the unit-scale cases
+    g.check("f64", "out", out, atol=3e-4, rtol=1e-4)
+    keys = ["model_idx_in_bag", "shift_idx", "segment_offset", "models", "state", "audio_length", "tag"]
+    got = np.array([[str(e[k]) for k in keys] for e in events])
+    assert got.shape == g.z["events"].shape and (got == g.z["events"]).all()

@@ -116,13 +116,49 @@ def apply_fixture(name: str, cfg: HTDemucsConfig, wseeds, bag_weights, mix: np.n
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **store)
 
 
+def separator_fixture(name: str, cfg: HTDemucsConfig, wseed: int, wav: np.ndarray, rseed: int, **params):
+    """`demucs.api.Separator.separate_tensor` of the reference (api.py:241-291) around a reference HTDemucs carrying
+    our synthetic weights.  The zoo loader (`get_model`: a network fetch) is bypassed by handing the instance its
+    model directly; everything `separate_tensor` itself does -- in-place normalise by the mono mean / std, apply_model,
+    de-normalise, restore `wav` -- is the reference's code.  sr = the model's rate (no resampling: julius is absent)."""
+    import_reference()
+    import demucs.api as ref_api
+    store = {"meta/wseed": np.array(wseed), "meta/length": np.array(wav.shape[-1]), "meta/rseed": np.array(rseed)}
+    for k, v in params.items():
+        store[f"meta/kw_{k}"] = np.array(v)
+    for tag, dtype in (("f32", torch.float32), ("f64", torch.float64)):
+        sep = ref_api.Separator.__new__(ref_api.Separator)
+        sep._model = build_reference_htdemucs(cfg, synthetic_state_dict(cfg, wseed), dtype)
+        sep._audio_channels, sep._samplerate = sep._model.audio_channels, sep._model.samplerate
+        events = []
+        sep.update_parameter(device="cpu", jobs=0, progress=False, callback=lambda d: events.append(dict(d)),
+                             callback_arg={"tag": "fixture"}, **params)
+        x = torch.from_numpy(wav).to(dtype)
+        x0 = x.clone()
+        random.seed(rseed)
+        t0 = time.time()
+        got_wav, stems = sep.separate_tensor(x, sr=sep.samplerate)
+        assert got_wav is x, "separate_tensor returns the caller's tensor"
+        print(f"  {name} {tag}: {time.time() - t0:.1f}s  {len(events)} events, restore err {(x - x0).abs().max():.2e}")
+        assert list(stems) == list(cfg.sources)
+        pack(f"{tag}/out", sample(torch.stack([stems[k] for k in cfg.sources]), 16384), store)
+        pack(f"{tag}/wav", sample(x, 4096), store)
+        store[f"{tag}/restore_err"] = np.array((x - x0).abs().max().item())
+        if tag == "f32":
+            keys = ["model_idx_in_bag", "shift_idx", "segment_offset", "models", "state", "audio_length", "tag"]
+            store["events"] = np.array([[str(e[k]) for k in keys] for e in events])
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **store)
+
+
 def main():
-    global segment_fixture, apply_fixture
+    global segment_fixture, apply_fixture, separator_fixture
     only = set(sys.argv[1:])
     if only:                                   # regenerate just the named fixtures
         seg_all, app_all = segment_fixture, apply_fixture
         segment_fixture = lambda n, *a, **k: seg_all(n, *a, **k) if n in only else None    # noqa: E731
         apply_fixture = lambda n, *a, **k: app_all(n, *a, **k) if n in only else None      # noqa: E731
+        sep_all = separator_fixture
+        separator_fixture = lambda n, *a, **k: sep_all(n, *a, **k) if n in only else None   # noqa: E731
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     cfg4 = HTDemucsConfig()
@@ -149,6 +185,10 @@ def main():
     apply_fixture("apply_nosplit_short", cfg4, [0], None, synth_mix(6, 200000, "tones"), shifts=0, split=False)
     apply_fixture("apply_overlap10_tp2", cfg4, [1], None, synth_mix(8, int(1.5 * SL), "noise"),
                   shifts=0, split=True, overlap=0.1, transition_power=2.0)
+    print("separator fixtures")
+    # a loud, DC-shifted input so that the mono mean / std normalisation of api.py:267-269 is far from the identity
+    separator_fixture("separator_shift1", cfg4, 3, 3.0 * synth_mix(12, int(1.3 * SL), "tones") + 0.2, rseed=11,
+                      shifts=1, overlap=0.25, split=True, segment=None)
 
 
 if __name__ == "__main__":
