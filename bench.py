@@ -78,6 +78,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-leg", action="store_true")
     ap.add_argument("--no-fixed-leg", action="store_true")
+    ap.add_argument("--no-modes-leg", action="store_true")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -225,6 +226,40 @@ def main():
                                      "note": "configs[3]'s 60-minute track on ONE GPU, HBM-resident like `value`: the N = 1 point of the "
                                              "fixed-length (strong-scaling) curve that `--gpus N > 1` continues"}
             del o, long_mix
+        if world == 1 and not args.no_modes_leg and args.dtype == "f32":
+            # the reduced-precision compute modes on the same 3-minute track (BASELINE configs[2]'s bf16, configs[4]'s fp16 +
+            # 6 sources): HBM-resident like `value`, own roofline against the dense bf16 / fp16 MFMA peak
+            result["modes"] = {}
+            mix3 = make_mix(TRACK_SECONDS)
+            cfg6 = HTDemucsConfig(sources=["drums", "bass", "other", "vocals", "guitar", "piano"])
+            for tag, mcfg, dt in (("htdemucs bf16", cfg, "bf16"), ("htdemucs_6s fp16", cfg6, "f16")):
+                m2 = HTDemucs(mcfg.sources, max_batch=args.batch, compute_dtype=dt)
+                m2.load_state_dict(sd if mcfg is cfg else synthetic_state_dict(mcfg, 0))
+                m2.to(dev).eval()
+                P.apply_model(m2, mix3, shifts=0, split=True, overlap=0.25, device=dev)
+                torch.cuda.synchronize(dev)
+                m2.profile_begin()
+                t1 = time.perf_counter()
+                for _ in range(3):
+                    o = P.apply_model(m2, mix3, shifts=0, split=True, overlap=0.25, device=dev)
+                torch.cuda.synchronize(dev)
+                dt_s = (time.perf_counter() - t1) / 3
+                rows2 = m2.profile_end()
+                assert bool(torch.isfinite(o[0, :, 0, ::997]).all())
+                d2 = max(rows2, key=lambda r: r["ms"])
+                tf = d2["flops"] / (d2["ms"] * 1e-3) / 1e12
+                result["modes"][tag] = {
+                    "dtype": dt, "sources": len(mcfg.sources), "value": round(TRACK_SECONDS / dt_s, 2), "unit": "audio-sec/wall-sec",
+                    "ms_per_step": round(dt_s * 1e3, 3), "steps": 3,
+                    "roofline": {"bound": "mfma", "kernel": d2["name"], "achieved": round(tf, 2), "peak": MFMA_PEAK_TFLOPS[dt], "unit": "TFLOP/s",
+                                 "frac": round(tf / MFMA_PEAK_TFLOPS[dt], 4), "avg_launch_ms": round(d2["ms"] / d2["launches"], 4),
+                                 "algorithmic_gbps": round(d2["bytes"] / (d2["ms"] * 1e-3) / 1e9, 1),
+                                 "note": "activations stay float32 in HBM in these modes: the class is HBM-bound long before the 2.5 PF pipe"},
+                    "kernels": [{"name": r["name"], "ms": round(r["ms"], 3), "tflops": round(r["flops"] / (r["ms"] * 1e-3) / 1e12, 1)}
+                                for r in sorted(rows2, key=lambda r: -r["ms"])[:6]]}
+                del o
+                m2.release()
+            del mix3
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(sd, cfg.sources)
         print(json.dumps(result), flush=True)

@@ -43,8 +43,8 @@ class MiConvDesc(C.Structure):
         ("bias", C.c_void_p), ("scale", C.c_void_p), ("res", C.c_void_p), ("emb", C.c_void_p),
         ("y", C.c_void_p), ("y_bstride", C.c_int64), ("y_cstride", C.c_int64),
         ("stats", C.c_void_p), ("gn_stats", C.c_void_p), ("gn_w", C.c_void_p), ("gn_b", C.c_void_p),
-        ("out_len", C.c_int32), ("tile_m", C.c_int32), ("plain", C.c_int32), ("reserved", C.c_int32),
-        ("o2_valid", C.c_int32), ("reserved2", C.c_int32), ("sink", C.c_void_p), ("wx", C.c_void_p),
+        ("out_len", C.c_int32), ("tile_m", C.c_int32), ("plain", C.c_int32), ("half", C.c_int32),
+        ("o2_valid", C.c_int32), ("ktab_len", C.c_int32), ("sink", C.c_void_p), ("wx", C.c_void_p), ("wh", C.c_void_p),
     ]
 
 
@@ -70,8 +70,9 @@ SIGNATURES = {
     "mi_resample_frac": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64,
                                    C.c_void_p]),
     "mi_conv_pack_split": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "mi_conv_pack_half": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "mi_attention": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
-                               C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_void_p]),
+                               C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_void_p]),
     "mi_gn_gelu": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                              C.c_void_p, C.c_void_p]),
     "mi_layernorm_cf": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,

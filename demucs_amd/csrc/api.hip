@@ -217,10 +217,15 @@ int mi_conv_pack_split(const float *wt_dev, int32_t Kpad, int32_t Mpad, int32_t 
     return launch_pack_split(wt_dev, Kpad, Mpad, tile_m, wx_dev, (hipStream_t)stream);
 }
 
+int mi_conv_pack_half(const float *wt_dev, int32_t Kpad, int32_t Mpad, int32_t dtype, void *wh_dev, void *stream) {
+    MI_REQUIRE(wt_dev && wh_dev && Kpad > 0 && Mpad > 0, "mi_conv_pack_half: bad argument");
+    return launch_pack_half(wt_dev, Kpad, Mpad, dtype, wh_dev, (hipStream_t)stream);
+}
+
 int mi_attention(const float *q_dev, const float *k_dev, const float *v_dev, float *o_dev, int32_t B, int32_t heads, int32_t Tq,
-                 int32_t Tk, int64_t q_batch_stride, int64_t kv_batch_stride, int64_t o_batch_stride, void *stream) {
+                 int32_t Tk, int64_t q_batch_stride, int64_t kv_batch_stride, int64_t o_batch_stride, int32_t dtype, void *stream) {
     MI_REQUIRE(q_dev && k_dev && v_dev && o_dev && B > 0 && heads > 0 && Tq > 0 && Tk > 0, "mi_attention: bad argument");
-    return launch_attention(q_dev, k_dev, v_dev, o_dev, B, heads, Tq, Tk, q_batch_stride, kv_batch_stride, o_batch_stride,
+    return launch_attention(q_dev, k_dev, v_dev, o_dev, B, heads, Tq, Tk, q_batch_stride, kv_batch_stride, o_batch_stride, dtype,
                             (hipStream_t)stream);
 }
 

@@ -69,14 +69,15 @@ typedef struct mi_conv_desc {
     int32_t tile_m;         /* 0 = choose automatically; else 32 / 64 / 96 / 128         */
     int32_t plain;          /* 1: the gather is the identity over input channels (1x1 conv / linear with channel
                                stride O1*O2): enables the table-free float4 loader when shapes allow             */
-    int32_t reserved;
+    int32_t half;           /* 0, or MI_DTYPE_BF16 / MI_DTYPE_F16 (include/demucs_amd.h): run the main loop of gemm_half.hip on `wh` */
     int32_t o2_valid;       /* 0, or the number of REAL positions along o2 when O2 is a padded row pitch (columns with
                                o2 >= o2_valid are computed but never stored nor counted): lets rows whose length is
                                not a multiple of 4 keep 16-byte aligned starts and use the float4 loader            */
-    int32_t reserved2;
+    int32_t ktab_len;       /* entries in ktab (0 = Kpad): the half-precision main loop steps K by 32 and needs Kpad rounded up to 32 */
     float *sink;            /* >= 256 floats that out-of-range epilogue stores are diverted to; NULL = library-owned */
     const void *wx;         /* NULL, or the weights as the split-bf16 tile image of mi_conv_pack_split for THIS tile_m:
                                selects the 6-product bf16 MFMA main loop (gemm_x6.hip) for tile_m 64 / 96 / 128     */
+    const void *wh;         /* `half` != 0: the weights as Wh[ceil(Kpad/32)*4][Mpad][8] bf16 / fp16 (mi_conv_pack_half)           */
 } mi_conv_desc;
 
 #ifdef __cplusplus

@@ -386,6 +386,7 @@ int launch_conv(const mi_conv_desc &din, hipStream_t st) {
     const int64_t P = (int64_t)d.O1 * d.O2;
     const bool plain = d.plain && d.K == d.Kpad && P % 4 == 0 && d.x_bstride % 4 == 0 && ((uintptr_t)d.x & 15) == 0 &&
                        d.S1 == 1 && d.S2 == 1 && d.D1 == d.O1 && d.D2 == d.O2;
+    if (d.half) return launch_conv_half(d, tile, plain, st);
     static const int x6_mode = getenv("MI_X6_MODE") ? atoi(getenv("MI_X6_MODE")) : 0;   // bisecting: 1 plain only, 2 gather only
     static const int x6_class = getenv("MI_X6_CLASS") ? atoi(getenv("MI_X6_CLASS")) : -1;   // bisecting: one kernel class only
     if (x6_class >= 0 && x6_class != d.epi * 8 + (tile == 32 ? 0 : tile == 64 ? 1 : tile == 96 ? 2 : 3) * 2 + (plain ? 1 : 0)) d.wx = nullptr;

@@ -1,0 +1,246 @@
+// Implicit-GEMM convolution / linear layer with bf16 or fp16 OPERANDS on the 16x matrix pipe
+// (v_mfma_f32_32x32x16_bf16 / _f16), fp32 accumulation: the engine's reduced-precision compute modes
+// (mi_config.dtype = MI_DTYPE_BF16 / MI_DTYPE_F16; BASELINE.json configs[2], configs[4]).
+//
+// Same contract as gemm_conv.hip (mi_conv_desc: table-driven gather, fused epilogues of gemm_tile.h); what changes:
+//   * weights are converted ONCE at load time into the LDS tile image  Wh[K/8][Mpad][8 x 2 bytes]  (k-octet major), so
+//     a 32x32x16 A fragment (lane l: row l & 31, k = 8 (l >> 5) .. +7) is one 16-byte word and a K step's tile is four
+//     contiguous BM x 16 B runs;
+//   * activations stay float32 in HBM (every norm / statistic / residual downstream reads them in float32); thread
+//     (column n, k half) loads its 16 k values of the K step (coalesced along n, through the same gather table),
+//     rounds them to the operand type (v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32, round-to-nearest-even) and writes two
+//     16-byte words of the B tile image  Bs[k octet][BN][8];
+//   * K step 32 = two MFMA k steps; LDS double buffer, global -> register prefetch of step k+1 under the MFMAs of k.
+// Bias, GroupNorm / LayerNorm statistics, GELU / GLU / sigmoid, LayerScale and residual adds run in float32 on the
+// float32 accumulators exactly as in the fp32 mode.
+#include "gemm_tile.h"
+
+namespace mi {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int HK = 32;      // K step of the half-precision main loop
+
+template <int HT>
+__device__ __forceinline__ unsigned pack2(float a, float b) {
+    if (HT == MI_DTYPE_BF16) {
+        const bf16x2 h = {(__bf16)a, (__bf16)b};
+        return __builtin_bit_cast(unsigned, h);
+    } else {
+        const f16x2 h = {(_Float16)a, (_Float16)b};
+        return __builtin_bit_cast(unsigned, h);
+    }
+}
+
+template <int HT>
+__device__ __forceinline__ f32x16 mfma16(const uint4 a, const uint4 b, const f32x16 c) {
+    if (HT == MI_DTYPE_BF16)
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+// Wt[Kpad][Mpad] fp32 -> Wh[Kh/8][Mpad][8] (Kh = Kpad rounded up to 32; the tail is zero)
+template <int HT>
+__global__ void pack_half_kernel(const float *__restrict__ wt, int Kpad, int Kh, int Mpad, unsigned short *__restrict__ wh) {
+    const size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (idx >= (size_t)Kh * Mpad) return;
+    const int k = (int)(idx / Mpad), m = (int)(idx % Mpad);
+    const float x = k < Kpad ? wt[idx] : 0.f;
+    const unsigned p = pack2<HT>(x, 0.f);
+    wh[((size_t)(k >> 3) * Mpad + m) * 8 + (k & 7)] = (unsigned short)(p & 0xffffu);
+}
+
+int launch_pack_half(const float *wt, int Kpad, int Mpad, int dtype, void *wh, hipStream_t st) {
+    MI_REQUIRE(dtype == MI_DTYPE_BF16 || dtype == MI_DTYPE_F16, "pack_half: dtype %d", dtype);
+    const int Kh = (Kpad + HK - 1) / HK * HK;
+    const size_t n = (size_t)Kh * Mpad;
+    if (dtype == MI_DTYPE_BF16)
+        hipLaunchKernelGGL(pack_half_kernel<MI_DTYPE_BF16>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, wt, Kpad, Kh, Mpad, (unsigned short *)wh);
+    else
+        hipLaunchKernelGGL(pack_half_kernel<MI_DTYPE_F16>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, wt, Kpad, Kh, Mpad, (unsigned short *)wh);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+
+template <int HT, int WM, int WN, int TM, int TN, int EPI, int LFLAGS, bool PLAIN>
+__global__ __launch_bounds__(256, 2) void conv_gemm_half_kernel(const mi_conv_desc d, const int N, const int MT, const int Gm) {
+    constexpr int BM = WM * TM * 32;
+    static_assert(WN * TN * 32 == BN, "block N tile is 128");
+    static_assert(WM * WN == 4, "4 waves");
+    __shared__ uint4 As[2][4][BM];
+    __shared__ uint4 Bs[2][4][BN];
+    {   // accumulators in AGPRs (see gemm_x6.hip: VGPR-form bf16 MFMA streams disturbed co-resident processes on this pool)
+        float agpr_anchor = 0.f;
+        asm volatile("; accumulators in AGPRs %0" : "+a"(agpr_anchor));
+    }
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    int mt, nt;
+    if (!tile_of_block(MT, Gm, N, mt, nt)) return;      // grid padding (whole workgroup, before any barrier)
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int P = d.O1 * d.O2;
+    const int o2v = d.o2_valid ? d.o2_valid : d.O2;
+    const int nk = (d.Kpad + HK - 1) / HK;
+
+    // ---- A loader: the K step's image is 4 runs of BM 16-byte words ----------------------------------
+    constexpr int A_W = 4 * BM, A_FULL = A_W / 256, A_REM = A_W % 256, A_SLOTS = A_FULL + (A_REM ? 1 : 0);
+    static_assert(A_SLOTS <= 2, "A tile fits two 16-byte words per thread");
+    const bool a_on0 = tid < A_W, a_on1 = tid + 256 < A_W;
+    const int ai0 = a_on0 ? tid : 0, ai1 = a_on1 ? tid + 256 : 0;
+    const int ao0 = ai0 / BM, am0 = ai0 % BM, ao1 = ai1 / BM, am1 = ai1 % BM;
+    const uint4 *wh = reinterpret_cast<const uint4 *>(d.wh);
+    const uint4 *ap0 = wh + (size_t)ao0 * d.Mpad + m0 + am0;
+    const uint4 *ap1 = wh + (size_t)ao1 * d.Mpad + m0 + am1;
+    const size_t a_step = (size_t)4 * d.Mpad;
+
+    // ---- B loader: thread = (column bn, k half bh): k = 16 bh .. 16 bh + 15 of the K step ---------------
+    const int bn = tid & 127;
+    const int bh = __builtin_amdgcn_readfirstlane(tid >> 7);
+    const ColInfo lc = decompose(n0 + bn, N, P, d.O2, PLAIN ? d.O2 : o2v);
+    const int i1b = lc.o1 * d.S1, i2b = lc.o2 * d.S2;
+    const float *xcol = d.x + (size_t)lc.b * d.x_bstride + (PLAIN ? (size_t)lc.p : (size_t)i1b * d.D2 + i2b);
+
+    uint4 areg0 = make_uint4(0, 0, 0, 0), areg1 = areg0;
+    float breg[16];
+
+#define MI_LOAD_TILE(kt)                                                                              \
+    do {                                                                                              \
+        if (PLAIN) {                                                                                  \
+            _Pragma("unroll") for (int j = 0; j < 16; ++j) {                                          \
+                const int c = (kt) * HK + 16 * bh + j;                                                \
+                const bool ok = lc.valid && c < d.K;                                                  \
+                const float v = *(ok ? xcol + (size_t)c * P : d.x);                                   \
+                breg[j] = ok ? v : 0.f;                                                               \
+            }                                                                                         \
+        } else {                                                                                      \
+            _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                           \
+                mi_ktab_entry ke[8];                                                                  \
+                _Pragma("unroll") for (int j = 0; j < 8; ++j) ke[j] = d.ktab[(kt) * HK + 16 * bh + 8 * h + j]; \
+                _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                       \
+                    bool ok;                                                                          \
+                    const float v = gather_b(d, ke[j], xcol, i1b, i2b, lc.valid, ok);                 \
+                    breg[8 * h + j] = ok ? v : 0.f;                                                   \
+                }                                                                                     \
+            }                                                                                         \
+        }                                                                                             \
+        if (A_SLOTS >= 1) areg0 = ap0[(size_t)(kt) * a_step];                                         \
+        if (A_SLOTS >= 2) areg1 = ap1[(size_t)(kt) * a_step];                                         \
+    } while (0)
+
+#define MI_STORE_TILE(buf)                                                                            \
+    do {                                                                                              \
+        _Pragma("unroll") for (int h = 0; h < 2; ++h)                                                 \
+            Bs[buf][2 * bh + h][bn] = make_uint4(pack2<HT>(breg[8 * h], breg[8 * h + 1]), pack2<HT>(breg[8 * h + 2], breg[8 * h + 3]), \
+                                                 pack2<HT>(breg[8 * h + 4], breg[8 * h + 5]), pack2<HT>(breg[8 * h + 6], breg[8 * h + 7])); \
+        if (A_SLOTS >= 1 && a_on0) As[buf][ao0][am0] = areg0;                                         \
+        if (A_SLOTS >= 2 && a_on1) As[buf][ao1][am1] = areg1;                                         \
+    } while (0)
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int li = lane & 31, lh = lane >> 5;
+    MI_LOAD_TILE(0);
+    MI_STORE_TILE(0);
+    __syncthreads();
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) MI_LOAD_TILE(kt + 1);
+        uint4 af[2][TM], bf[2][TN];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+#pragma unroll
+            for (int a = 0; a < TM; ++a) af[s][a] = As[cur][2 * s + lh][(wm * TM + a) * 32 + li];
+#pragma unroll
+            for (int b = 0; b < TN; ++b) bf[s][b] = Bs[cur][2 * s + lh][(wn * TN + b) * 32 + li];
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b) acc[a][b] = mfma16<HT>(af[s][a], bf[s][b], acc[a][b]);
+        if (kt + 1 < nk) MI_STORE_TILE(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+#undef MI_LOAD_TILE
+#undef MI_STORE_TILE
+    conv_epilogue<TM, TN, EPI, LFLAGS>(d, acc, m0, n0, wm, wn, N, P, o2v);
+}
+
+template <int HT, int WM, int WN, int TM, int TN, int EPI, int LFLAGS, bool PLAIN>
+static int launch_cfg_half(const mi_conv_desc &d, hipStream_t st) {
+    constexpr int BM = WM * TM * 32;
+    const int64_t N64 = (int64_t)d.B * d.O1 * d.O2;
+    MI_REQUIRE(N64 < (1ll << 31) - 256, "conv: too many output positions (%lld)", (long long)N64);
+    MI_REQUIRE(d.Mpad % BM == 0, "conv: Mpad %d not a multiple of the %d-row tile", d.Mpad, BM);
+    const int N = (int)N64, MT = d.Mpad / BM, NT = ceil_div(N, BN);
+    const int Gm = 1;
+    const unsigned grid = grouped_grid(MT, NT, Gm);
+    hipLaunchKernelGGL((conv_gemm_half_kernel<HT, WM, WN, TM, TN, EPI, LFLAGS, PLAIN>), dim3(grid), dim3(256), 0, st, d, N, MT, Gm);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+
+template <int HT, int EPI, int LFLAGS, bool PLAIN>
+static int launch_tile_half(const mi_conv_desc &d, int tile, hipStream_t st) {
+    switch (tile) {
+        case 128: return launch_cfg_half<HT, 2, 2, 2, 2, EPI, LFLAGS, PLAIN>(d, st);
+        case 96: return launch_cfg_half<HT, 1, 4, 3, 1, EPI, LFLAGS, PLAIN>(d, st);
+        case 64: return launch_cfg_half<HT, 1, 4, 2, 1, EPI, LFLAGS, PLAIN>(d, st);
+        case 32: return launch_cfg_half<HT, 1, 4, 1, 1, EPI, LFLAGS, PLAIN>(d, st);
+    }
+    return set_error(MI_EINVAL, "conv half: unsupported tile_m %d", tile);
+}
+
+template <int HT>
+static int launch_conv_half_t(const mi_conv_desc &d, int tile, bool plain, hipStream_t st) {
+#define MI_DISPATCH(E)                                              \
+    case E: return plain ? launch_tile_half<HT, E, 0, true>(d, tile, st) : launch_tile_half<HT, E, 0, false>(d, tile, st)
+#define MI_LINEAR(F)                                                \
+    case F: return plain ? launch_tile_half<HT, MI_EPI_LINEAR, F, true>(d, tile, st) : launch_tile_half<HT, MI_EPI_LINEAR, F, false>(d, tile, st)
+    if (d.epi == MI_EPI_LINEAR) {
+        switch (d.flags & (MI_FLAG_GELU | MI_FLAG_SCALE | MI_FLAG_RES | MI_FLAG_LN)) {
+            MI_LINEAR(0);
+            MI_LINEAR(MI_FLAG_GELU);
+            MI_LINEAR(MI_FLAG_RES);
+            MI_LINEAR(MI_FLAG_SCALE | MI_FLAG_RES);
+            MI_LINEAR(MI_FLAG_LN);
+            MI_LINEAR(MI_FLAG_LN | MI_FLAG_GELU);
+        }
+        return set_error(MI_EINVAL, "conv: unsupported LINEAR flag combination %d", d.flags);
+    }
+#undef MI_LINEAR
+    switch (d.epi) {
+        MI_DISPATCH(MI_EPI_GLU);
+        MI_DISPATCH(MI_EPI_BIAS_STATS);
+        MI_DISPATCH(MI_EPI_STATS_ONLY);
+        MI_DISPATCH(MI_EPI_GN_GLU);
+        MI_DISPATCH(MI_EPI_CONVTR);
+    }
+#undef MI_DISPATCH
+    return set_error(MI_EINVAL, "conv: unsupported epilogue %d", d.epi);
+}
+
+// d has been validated by launch_conv (gemm_conv.hip), which also decided `plain`
+int launch_conv_half(const mi_conv_desc &d, int tile, bool plain, hipStream_t st) {
+    MI_REQUIRE(d.wh && ((uintptr_t)d.wh & 15) == 0, "conv half: weight image missing or misaligned");
+    MI_REQUIRE(plain || d.ktab_len >= (d.Kpad + HK - 1) / HK * HK, "conv half: gather table has %d entries, the K step of %d needs %d",
+               d.ktab_len, HK, (d.Kpad + HK - 1) / HK * HK);
+    if (d.half == MI_DTYPE_BF16) return launch_conv_half_t<MI_DTYPE_BF16>(d, tile, plain, st);
+    if (d.half == MI_DTYPE_F16) return launch_conv_half_t<MI_DTYPE_F16>(d, tile, plain, st);
+    return set_error(MI_EINVAL, "conv half: operand type %d", d.half);
+}
+
+}  // namespace mi

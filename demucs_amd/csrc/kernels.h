@@ -60,9 +60,13 @@ bool conv_x6_supported(int tile);
 int launch_conv_x6(const mi_conv_desc &d, int tile, bool plain, hipStream_t st);
 int launch_pack_split(const float *wt, int Kpad, int Mpad, int tile_m, void *wx, hipStream_t st);
 
+// gemm_half.hip: bf16 / fp16 operand main loop (mi_config.dtype)
+int launch_conv_half(const mi_conv_desc &d, int tile, bool plain, hipStream_t st);
+int launch_pack_half(const float *wt, int Kpad, int Mpad, int dtype, void *wh, hipStream_t st);
+
 // attention.hip
 int launch_attention(const float *q, const float *k, const float *v, float *o, int B, int heads, int Tq, int Tk, int64_t q_bs,
-                     int64_t kv_bs, int64_t o_bs, hipStream_t st);
+                     int64_t kv_bs, int64_t o_bs, int dtype, hipStream_t st);
 
 // ola.hip
 int launch_segments_gather(const float *track, int64_t track_len, int channels, const int64_t *starts_dev, int B, int valid,

@@ -17,7 +17,8 @@ struct Geo;
 struct PackedConv {
     float *wt = nullptr, *bias = nullptr;
     void *wx = nullptr;            // split-bf16 tile image of wt (gemm_x6.hip) when the tile has that main loop
-    int M = 0, Mpad = 0, K = 0, Kpad = 0, tile = 0;
+    void *wh = nullptr;            // bf16 / fp16 operand image of wt (gemm_half.hip) in the reduced-precision modes
+    int M = 0, Mpad = 0, K = 0, Kpad = 0, tile = 0, half = 0;
 };
 
 struct DConvLayerW {
@@ -131,6 +132,7 @@ struct Model : WorkspacePtrs {
     int dev_alloc(void **p, size_t bytes);
     template <typename T> int upload(const std::vector<T> &h, T **dptr);
     int pack_split(PackedConv *pc);
+    int pack_half(PackedConv *pc);
     int pack_conv(const float *W, const float *bias, int M, int K, bool glu, PackedConv *pc);
     int pack_convtr(const float *W, const float *bias, int Cin, int Cout, PackedConv *pc);
     int pack_vec(const float *v, int n, int npad, bool glu, float **out);

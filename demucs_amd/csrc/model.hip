@@ -81,7 +81,7 @@ static const char *kEpiNames[6] = {"linear", "glu", "bias_stats", "stats_only", 
 // class id of a conv launch: epilogue x tile x prologue
 static int conv_class(const mi_conv_desc &d, int tile) {
     const int ti = tile == 32 ? 0 : tile == 64 ? 1 : tile == 96 ? 2 : 3;
-    const bool x6 = d.wx && conv_x6_supported(tile);                 // split-bf16 main loop (gemm_x6.hip): own classes
+    const bool x6 = d.half || (d.wx && conv_x6_supported(tile));     // bf16 / fp16 operand or split-bf16 main loops: own classes
     return (x6 ? 48 : 0) + d.epi * 8 + ti * 2 + (d.plain ? 1 : 0);
 }
 
@@ -105,22 +105,23 @@ int Model::conv(const mi_conv_desc &d, hipStream_t st) {
     prof.pending.push_back(p);
     ProfRow &row = prof.rows[cls];
     if (!row.name[0])
-        snprintf(row.name, sizeof(row.name), "conv_gemm%s<%s,tile%d%s>", cls >= 48 ? "_x6" : "", kEpiNames[d.epi], tile, d.plain ? ",1x1" : "");
+        snprintf(row.name, sizeof(row.name), "conv_gemm%s<%s,tile%d%s>", d.half == MI_DTYPE_BF16 ? "_bf16" : d.half == MI_DTYPE_F16 ? "_f16" : cls >= 48 ? "_x6" : "",
+                 kEpiNames[d.epi], tile, d.plain ? ",1x1" : "");
     return r;
 }
 
 int Model::attn(const float *q, const float *k, const float *v, float *o, int B, int Tq, int Tk, int64_t q_bs, int64_t kv_bs,
                 int64_t o_bs, hipStream_t st) {
-    if (!prof.on) return launch_attention(q, k, v, o, B, 8, Tq, Tk, q_bs, kv_bs, o_bs, st);
+    if (!prof.on) return launch_attention(q, k, v, o, B, 8, Tq, Tk, q_bs, kv_bs, o_bs, cfg.dtype, st);
     const int cls = 100;
     // QK^T and PV: 2 * 2 * Tq * Tk * 64 flops per head; bytes = q, k, v read once + o written
     Profiler::Pending p{cls, prof.get(), prof.get(), 4.0 * B * 8 * (double)Tq * Tk * 64.0,
                         4.0 * B * 512.0 * (2.0 * Tq + 2.0 * Tk)};
     MI_HIP(hipEventRecord(p.a, st));
-    const int r = launch_attention(q, k, v, o, B, 8, Tq, Tk, q_bs, kv_bs, o_bs, st);
+    const int r = launch_attention(q, k, v, o, B, 8, Tq, Tk, q_bs, kv_bs, o_bs, cfg.dtype, st);
     MI_HIP(hipEventRecord(p.b, st));
     prof.pending.push_back(p);
-    snprintf(prof.rows[cls].name, sizeof(prof.rows[cls].name), "attention_kernel");
+    snprintf(prof.rows[cls].name, sizeof(prof.rows[cls].name), "attention%s_kernel", cfg.dtype == MI_DTYPE_BF16 ? "_bf16" : cfg.dtype == MI_DTYPE_F16 ? "_f16" : "");
     return r;
 }
 
@@ -182,6 +183,17 @@ int Model::pack_split(PackedConv *pc) {
     return MI_OK;
 }
 
+// Reduced-precision compute modes: the weights a second time as the bf16 / fp16 operand image of gemm_half.hip
+int Model::pack_half(PackedConv *pc) {
+    if (cfg.dtype == MI_DTYPE_F32) return MI_OK;
+    const int Kh = round_up(pc->Kpad, 32);
+    MI_TRY(dev_alloc(&pc->wh, (size_t)2 * Kh * pc->Mpad));
+    pc->half = cfg.dtype;
+    MI_TRY(launch_pack_half(pc->wt, pc->Kpad, pc->Mpad, cfg.dtype, pc->wh, nullptr));
+    MI_HIP(hipStreamSynchronize(nullptr));
+    return MI_OK;
+}
+
 // Conv / Linear weights W[M][K] (K = Cin*K1*K2 flattened) -> Wt[Kpad][Mpad]; `glu` interleaves the
 // two GLU halves: packed row 2c = W[c], 2c+1 = W[c + M/2].
 int Model::pack_conv(const float *W, const float *bias, int M, int K, bool glu, PackedConv *pc) {
@@ -195,6 +207,7 @@ int Model::pack_conv(const float *W, const float *bias, int M, int K, bool glu, 
     }
     MI_TRY(upload(wt, &pc->wt));
     MI_TRY(upload(b, &pc->bias));
+    MI_TRY(pack_half(pc));
     return pack_split(pc);
 }
 
@@ -214,6 +227,7 @@ int Model::pack_convtr(const float *W, const float *bias, int Cin, int Cout, Pac
         for (int r = 0; r < 4; ++r) b[4 * co + r] = bias[co];
     MI_TRY(upload(wt, &pc->wt));
     MI_TRY(upload(b, &pc->bias));
+    MI_TRY(pack_half(pc));
     return pack_split(pc);
 }
 
@@ -242,7 +256,7 @@ int Model::pack_vec(const float *v, int n, int npad, bool glu, float **out) {
 }
 
 int Model::make_ktab(const Gather &g, int Kpad, mi_ktab_entry **out) {
-    return upload(build_ktab(g, Kpad), out);
+    return upload(build_ktab(g, round_up(Kpad, 32)), out);     // entries past Kpad are "never valid": the K step of 32 of gemm_half.hip
 }
 
 int Model::load_dconv(const WeightTable &wt, const std::string &prefix, int C, int64_t chan_stride, int D2, bool freq, DConvW *dw) {
@@ -305,7 +319,7 @@ int Model::init(const mi_config &c, const mi_tensor_desc *weights, size_t n) {
     cfg = c;
     MI_REQUIRE(c.n_sources >= 1 && c.n_sources <= 8, "n_sources %d unsupported", c.n_sources);
     MI_REQUIRE(c.max_batch >= 1 && c.max_batch <= 64, "max_batch %d out of range [1, 64]", c.max_batch);
-    MI_REQUIRE(c.dtype == MI_DTYPE_F32, "compute dtype %d not available in this build", c.dtype);
+    MI_REQUIRE(c.dtype == MI_DTYPE_F32 || c.dtype == MI_DTYPE_BF16 || c.dtype == MI_DTYPE_F16, "unknown compute dtype %d", c.dtype);
     MI_REQUIRE(c.segment_length > 4096 && c.segment_length % 4 == 0, "segment_length %d unsupported", c.segment_length);
     S = c.n_sources; SL = c.segment_length; T = (SL + 1023) / 1024;
     MI_REQUIRE(T % 4 == 0, "segment_length %d gives %d STFT frames; the engine needs a multiple of 4", SL, T);
@@ -603,6 +617,7 @@ static mi_conv_desc base_desc(const PackedConv &pc, const mi_ktab_entry *ktab, c
     mi_conv_desc d;
     memset(&d, 0, sizeof(d));
     d.wt = pc.wt; d.M = pc.M; d.Mpad = pc.Mpad; d.K = pc.K; d.Kpad = pc.Kpad; d.ktab = ktab; d.bias = pc.bias; d.tile_m = pc.tile; d.wx = pc.wx;
+    d.wh = pc.wh; d.half = pc.wh ? pc.half : 0; d.ktab_len = round_up(pc.Kpad, 32);
     d.x = x; d.x_bstride = x_bs; d.B = g.B; d.D1 = g.D1; d.D2 = g.D2; d.O1 = g.D1; d.O2 = g.pitch(); d.S1 = 1; d.S2 = 1;
     d.o2_valid = g.pitch() != g.D2 ? g.D2 : 0;       // enumerate the padded row, mask the padding columns
     d.row_mode = g.row_mode;

@@ -159,12 +159,19 @@ int mi_conv_forward(const struct mi_conv_desc *desc, void *stream);
  *   tile_m must be the tile the layer will run with (64, 96 or 128). */
 int mi_conv_pack_split(const float *wt_dev, int32_t Kpad, int32_t Mpad, int32_t tile_m, void *wx_dev, void *stream);
 
+/* Converts fp32 weights Wt[Kpad][Mpad] (the mi_conv_desc.wt layout) into the bf16 / fp16 operand image
+ *   Wh[ceil(Kpad/32)*4][Mpad][8] (2 * round_up(Kpad, 32) * Mpad bytes) that mi_conv_desc.wh takes when mi_conv_desc.half
+ *   = MI_DTYPE_BF16 / MI_DTYPE_F16 (the load-time half of the reduced-precision compute modes; no reference counterpart). */
+int mi_conv_pack_half(const float *wt_dev, int32_t Kpad, int32_t Mpad, int32_t dtype, void *wh_dev, void *stream);
+
 /* Multi-head attention core softmax(QK^T/sqrt(64))V on channel-first tensors (stands in for the
  *   attention inside nn.MultiheadAttention, called at demucs/transformer.py:418-419,506):
- *   q_dev (B, heads*64, Tq) with row stride q_ld..., see demucs_amd/csrc/attention.h. */
+ *   q_dev (B, heads*64, Tq), k_dev / v_dev (B, heads*64, Tk), tokens contiguous, with the given batch strides; o_dev like
+ *   q_dev.  dtype = MI_DTYPE_F32 (fp32 MFMA, parity mode) or MI_DTYPE_BF16 / MI_DTYPE_F16 (operands of both products
+ *   rounded to that type, float32 softmax and accumulation). */
 int mi_attention(const float *q_dev, const float *k_dev, const float *v_dev, float *o_dev, int32_t B, int32_t heads,
                  int32_t Tq, int32_t Tk, int64_t q_batch_stride, int64_t kv_batch_stride, int64_t o_batch_stride,
-                 void *stream);
+                 int32_t dtype, void *stream);
 
 /* In-place GroupNorm(1, C) + GELU of the first C channels of x (B, C_alloc, D1, D2) given per-row (mean, rstd) float2 statistics
  *   (row = b*D1 + d1 if row_mode else b): the norm/activation pair inside DConv (demucs/demucs.py:139). */

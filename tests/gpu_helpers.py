@@ -53,6 +53,7 @@ def pack_vec(v, Mpad, glu=False):
 
 
 def ktab(Cin, K1, K2, dil1, dil2, pad1, pad2, chan_stride, D2, Kpad):
+    Kpad = rup(Kpad, 32)          # the bf16 / fp16 main loop steps K by 32: entries past K are "never valid"
     t = np.zeros((Kpad, 4), dtype=np.int32)
     K = Cin * K1 * K2
     for k in range(Kpad):
@@ -70,7 +71,17 @@ def conv_call(**kw):
     """Fill a MiConvDesc from keyword arguments (tensors -> data_ptr) and launch."""
     d = _lib.MiConvDesc()
     keep = []
-    if kw.pop("x6", False) and kw.get("tile_m") in (64, 96, 128):
+    mode = kw.pop("x6", False)
+    if mode in ("bf16", "f16"):
+        # reduced-precision compute mode: bf16 / fp16 operand image of the same packed weights (gemm_half.hip)
+        dt = {"bf16": 1, "f16": 2}[mode]
+        wh = torch.empty(2 * rup(kw["Kpad"], 32) * kw["Mpad"], dtype=torch.uint8, device="cuda")
+        _lib.check(_lib.load().mi_conv_pack_half(kw["wt"].data_ptr(), kw["Kpad"], kw["Mpad"], dt, wh.data_ptr(),
+                                                 C.c_void_p(_lib.current_stream_ptr())), "mi_conv_pack_half")
+        kw["wh"], kw["half"] = wh, dt
+        kw["ktab_len"] = kw["ktab"].shape[0] if isinstance(kw.get("ktab"), torch.Tensor) else 0
+        mode = False
+    if mode and kw.get("tile_m") in (64, 96, 128):
         # split-bf16 image of the same packed weights: selects the 6-product bf16 MFMA main loop
         wx = torch.empty(6 * kw["Kpad"] * kw["Mpad"], dtype=torch.uint8, device="cuda")
         _lib.check(_lib.load().mi_conv_pack_split(kw["wt"].data_ptr(), kw["Kpad"], kw["Mpad"], kw["tile_m"], wx.data_ptr(),

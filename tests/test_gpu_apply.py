@@ -148,11 +148,11 @@ def test_full_size_track_properties():
         assert err <= TOL, (k, err)
 
 
-def _bag4(max_batch, wrap=lambda m: m):
+def _bag4(max_batch, wrap=lambda m: m, compute_dtype="f32"):
     cfg = HTDemucsConfig()
     models = []
     for seed in (10, 11, 12, 13):
-        m = HTDemucs(cfg.sources, max_batch=max_batch)
+        m = HTDemucs(cfg.sources, max_batch=max_batch, compute_dtype=compute_dtype)
         m.load_state_dict(synthetic_state_dict(cfg, seed))
         models.append(wrap(m.to("cuda")))
     onehot = [[1.0 if i == k else 0.0 for k in range(4)] for i in range(4)]          # remote/htdemucs_ft.yaml
@@ -245,3 +245,53 @@ def test_separator_separate_tensor_matches_reference_separator(golden):
     got = np.array([[str(e[k]) for k in keys] for e in events])
     assert got.shape == g.z["events"].shape and (got == g.z["events"]).all()
     print(f"separator: max-abs vs reference f64 {e64:.2e} (de-normalisation gain {gain:.2f})")
+
+
+def test_config3_bf16_mode_full_size_and_miniature(golden):
+    """BASELINE configs[2] as written: htdemucs_ft-shaped bag of 4, shifts=2, overlap 0.25, bf16 compute mode.
+    (1) the miniature with a reference golden (`apply_bag4_onehot_shifts2`, float64 reference run): SDR >= 28 dB;
+    (2) the full 3-minute track: finite and >= 28 dB SDR per source against the float32 mode of the same engine."""
+    from oracle import apply_oracle as A
+    g = golden("apply_bag4_onehot_shifts2")
+    kw = golden_kwargs(g)
+    bag = _bag4(8, compute_dtype="bf16")
+    random.seed(int(g.meta("rseed")))
+    out = P.apply_model(bag, torch.from_numpy(CASES["apply_bag4_onehot_shifts2"]["mix"]())[None], device="cuda", **kw)
+    stride = int(g.z["f64/out/stride"])
+    want = g.z["f64/out/sample"].astype(np.float64)
+    got = out.reshape(-1)[::stride].double().numpy()
+    sdr = 10 * np.log10((np.sum(want * want) + 1e-7) / (np.sum((got - want) ** 2) + 1e-7))
+    print(f"bag4 shifts2 bf16 miniature: max-abs {np.abs(got - want).max():.3e}  SDR {sdr:.1f} dB vs the float64 reference")
+    assert sdr >= 28.0
+    length = 180 * 44100
+    mix = torch.from_numpy(synth_mix(1, length, "noise"))[None]
+    random.seed(0)
+    lo = P.apply_model(_bag4(32, compute_dtype="bf16"), mix, shifts=2, overlap=0.25, device="cuda")
+    random.seed(0)
+    hi = P.apply_model(_bag4(32), mix, shifts=2, overlap=0.25, device="cuda")
+    assert lo.shape == (1, 4, 2, length) and bool(torch.isfinite(lo).all())
+    sdrs = A.new_sdr(hi, lo)
+    print(f"bag4 shifts2 bf16 full size: per-source SDR vs the float32 mode {[round(float(v), 1) for v in sdrs.flatten()]} dB, "
+          f"max-abs {float((hi - lo).abs().max()):.3e}")
+    assert float(sdrs.min()) >= 28.0
+
+
+def test_config5_htdemucs_6s_fp16_track():
+    """BASELINE configs[4], first half: the 6-source model (htdemucs_6s architecture) in the fp16 compute mode on a
+    3-minute track.  Finite, (1, 6, 2, L), and >= 44 dB SDR per source against the float32 mode of the same engine
+    (the fp16 floor measured against the reference's float64 output is in tests/test_gpu_model.py)."""
+    from oracle import apply_oracle as A
+    cfg6 = HTDemucsConfig(sources=["drums", "bass", "other", "vocals", "guitar", "piano"])
+    sd = synthetic_state_dict(cfg6, 2)
+    length = 180 * 44100
+    mix = torch.from_numpy(synth_mix(1, length, "noise"))[None].cuda()
+    outs = {}
+    for dt in ("f16", "f32"):
+        m = HTDemucs(cfg6.sources, max_batch=16, compute_dtype=dt)
+        m.load_state_dict(sd)
+        outs[dt] = P.apply_model(m, mix, shifts=0, overlap=0.25, device="cuda")
+        m.release()
+    assert outs["f16"].shape == (1, 6, 2, length) and bool(torch.isfinite(outs["f16"]).all())
+    sdrs = A.new_sdr(outs["f32"].cpu(), outs["f16"].cpu())
+    print(f"htdemucs_6s fp16 track: per-source SDR vs float32 mode {[round(float(v), 1) for v in sdrs.flatten()]} dB")
+    assert float(sdrs.min()) >= 44.0

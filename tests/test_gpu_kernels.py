@@ -30,9 +30,24 @@ def stream():
     return C.c_void_p(_lib.current_stream_ptr())
 
 
+_HALF_MODE = [None]      # set by the `x6` fixture: "bf16" / "f16" while a reduced-precision case runs
+
+
 def rnd(*shape, seed=0, scale=1.0):
     g = torch.Generator().manual_seed(seed)
-    return torch.randn(*shape, generator=g, dtype=torch.float64) * scale
+    t = torch.randn(*shape, generator=g, dtype=torch.float64) * scale
+    if _HALF_MODE[0]:
+        # values exactly representable in bf16 AND fp16: the operand rounding of the reduced-precision GEMMs is then the
+        # identity, products are exact in float32, and the SAME tolerances as the float32 kernels apply to them
+        t = t.float().bfloat16().double()
+        t = torch.where(t.abs() < 2.0 ** -14, torch.zeros_like(t), t)
+    return t
+
+
+def chained_tol(base):
+    """Tolerance of a test whose kernel feeds COMPUTED values (not `rnd` ones) back into a matrix product: the operand
+    rounding (2^-9 relative for bf16, 2^-12 for fp16) is then visible."""
+    return {None: base, "bf16": max(base, 3e-2), "f16": max(base, 4e-3)}[_HALF_MODE[0]]
 
 
 # ------------------------------------------------------------------------------------------------
@@ -75,10 +90,13 @@ from gpu_helpers import (EPI_BIAS_STATS, EPI_CONVTR, EPI_GLU, EPI_GN_GLU, EPI_LI
                          FLAG_GELU, FLAG_RES, FLAG_SCALE, FLAG_TR_FREQ, SLOTS, conv_call, ktab, maxerr, pack_vec, pack_w)
 
 
-@pytest.fixture(params=[False, True], ids=["fp32mfma", "bf16x6"])
+@pytest.fixture(params=[False, True, "bf16", "f16"], ids=["fp32mfma", "bf16x6", "bf16", "f16"])
 def x6(request):
-    """Both GEMM main loops: native fp32 MFMA and the exact 3-term bf16 split with 6 products (gemm_x6.hip)."""
-    return request.param
+    """Every GEMM main loop: native fp32 MFMA, the exact 3-term bf16 split with 6 products (gemm_x6.hip), and the
+    reduced-precision compute modes with bf16 / fp16 operands (gemm_half.hip)."""
+    _HALF_MODE[0] = request.param if isinstance(request.param, str) else None
+    yield request.param
+    _HALF_MODE[0] = None
 
 
 def test_conv_freq_strided_gelu(lib, x6):
@@ -243,10 +261,11 @@ def test_dconv_layer_three_passes(lib, freq, x6):
     out = torch.empty_like(xd)
     conv_call(x6=x6, epi=EPI_GN_GLU, gn_stats=st2, gn_w=pack_vec(g2w, Mpad3, glu=True), gn_b=pack_vec(g2b, Mpad3, glu=True),
               scale=ls.float().cuda(), res=xd, y=out, y_bstride=C * P, y_cstride=P, **common)
-    assert maxerr(out, want) < 3e-5
+    assert maxerr(out, want) < chained_tol(3e-5)
 
 
-def test_attention_matches_softmax(lib):
+@pytest.mark.parametrize("dtype", [0, 1, 2], ids=["f32", "bf16", "f16"])
+def test_attention_matches_softmax(lib, dtype):
     """softmax(QK^T/8)V per head on channel-first q/k/v, ragged Tq (not a multiple of 128), cross
     lengths, and one spiked key forcing a large running-max jump mid-stream."""
     B, H, Tq, Tk = 2, 8, 200, 320
@@ -260,9 +279,10 @@ def test_attention_matches_softmax(lib):
     o = torch.empty(B, 512, Tq, device="cuda")
     qd = q.float().cuda()
     _lib.check(lib.mi_attention(qd.data_ptr(), kv.data_ptr(), kv.data_ptr() + 512 * Tk * 4, o.data_ptr(), B, H, Tq, Tk, 512 * Tq,
-                                1024 * Tk, 512 * Tq, stream()), "mi_attention")
+                                1024 * Tk, 512 * Tq, dtype, stream()), "mi_attention")
     torch.cuda.synchronize()
-    assert maxerr(o, want) < 2e-5
+    # half modes: Q, K, V and the probabilities are rounded to the operand type (2^-9 / 2^-12 relative), softmax in float32
+    assert maxerr(o, want) < [2e-5, 6e-2, 8e-3][dtype]        # scores reach |s| ~ 30 at the spiked key: 2^-9 (2^-12) relative on them moves a probability by several percent
 
 
 def test_layernorm_channel_first(lib):

@@ -150,13 +150,45 @@ def separator_fixture(name: str, cfg: HTDemucsConfig, wseed: int, wav: np.ndarra
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **store)
 
 
+def autocast_fixture(name: str, cfg: HTDemucsConfig, wseed: int, mix: np.ndarray):
+    """Noise floor for the engine's reduced-precision modes: the reference's own float32 model run under
+    `torch.autocast("cpu", dtype=bfloat16 / float16)` (conv / linear / attention matmuls in the low-precision type,
+    normalisations and the STFT in float32 by autocast's op lists), beside its float64 run of the same input."""
+    store = {"meta/wseed": np.array(wseed), "meta/n_sources": np.array(len(cfg.sources))}
+    sd = synthetic_state_dict(cfg, wseed)
+    x = torch.from_numpy(mix)[None]
+    runs = [("f64", torch.float64, None), ("bf16", torch.float32, torch.bfloat16), ("f16", torch.float32, torch.float16)]
+    for tag, dtype, cast in runs:
+        model = build_reference_htdemucs(cfg, sd, dtype)
+        t0 = time.time()
+        with torch.no_grad():
+            if cast is None:
+                out = model(x.to(dtype))
+            else:
+                with torch.autocast("cpu", dtype=cast):
+                    out = model(x)
+        out = out.double()
+        print(f"  {name} {tag}: {time.time() - t0:.1f}s  out rms {out.pow(2).mean().sqrt():.4f}")
+        if tag == "f64":
+            truth = out
+        else:
+            err = out - truth
+            store[f"{tag}/max_abs"] = np.array(err.abs().max().item())
+            store[f"{tag}/sdr_db"] = np.array((10 * torch.log10((truth.pow(2).sum((2, 3)) + 1e-7) / (err.pow(2).sum((2, 3)) + 1e-7))).min().item())
+            print(f"    vs f64: max-abs {store[tag + '/max_abs']:.3e}  min SDR {store[tag + '/sdr_db']:.1f} dB")
+        pack(f"{tag}/out", sample(out, 16384), store)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **store)
+
+
 def main():
-    global segment_fixture, apply_fixture, separator_fixture
+    global segment_fixture, apply_fixture, separator_fixture, autocast_fixture
     only = set(sys.argv[1:])
     if only:                                   # regenerate just the named fixtures
         seg_all, app_all = segment_fixture, apply_fixture
         segment_fixture = lambda n, *a, **k: seg_all(n, *a, **k) if n in only else None    # noqa: E731
         apply_fixture = lambda n, *a, **k: app_all(n, *a, **k) if n in only else None      # noqa: E731
+        ac_all = autocast_fixture
+        autocast_fixture = lambda n, *a, **k: ac_all(n, *a, **k) if n in only else None     # noqa: E731
         sep_all = separator_fixture
         separator_fixture = lambda n, *a, **k: sep_all(n, *a, **k) if n in only else None   # noqa: E731
     os.makedirs(OUT, exist_ok=True)
@@ -185,6 +217,9 @@ def main():
     apply_fixture("apply_nosplit_short", cfg4, [0], None, synth_mix(6, 200000, "tones"), shifts=0, split=False)
     apply_fixture("apply_overlap10_tp2", cfg4, [1], None, synth_mix(8, int(1.5 * SL), "noise"),
                   shifts=0, split=True, overlap=0.1, transition_power=2.0)
+    print("autocast (reduced-precision noise floor) fixtures")
+    autocast_fixture("autocast_seg_tones_w1", cfg4, 1, synth_mix(7, SL, "tones"))
+    autocast_fixture("autocast_seg6_noise_w2", cfg6, 2, synth_mix(11, SL, "noise"))
     print("separator fixtures")
     # a loud, DC-shifted input so that the mono mean / std normalisation of api.py:267-269 is far from the identity
     separator_fixture("separator_shift1", cfg4, 3, 3.0 * synth_mix(12, int(1.3 * SL), "tones") + 0.2, rseed=11,
