@@ -77,6 +77,7 @@ SIGNATURES = {
                              C.c_void_p, C.c_void_p]),
     "mi_layernorm_cf": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p]),
+    "mi_debug_set_post_launch_hook": (None, [C.c_void_p]),
     "mi_last_error": (C.c_char_p, []),
     "mi_version": (C.c_char_p, []),
 }

@@ -23,7 +23,17 @@ int set_error(int code, const char *fmt, ...);
                                  __FILE__, __LINE__);                                             \
     } while (0)
 
-#define MI_CHECK_LAUNCH() MI_HIP(hipGetLastError())
+// Debug aid (tools/micro/poison_all.py): a hook called after EVERY kernel launch of the engine with the launch stream, so that
+// a test can interleave a kernel that overwrites all VGPRs / AGPRs / LDS of the chip and show whether any engine kernel
+// consumes state it did not write (what a co-resident process of another application would leave behind).
+typedef void (*post_launch_hook_t)(void *stream);
+extern post_launch_hook_t g_post_launch_hook;
+
+#define MI_CHECK_LAUNCH()                                                   \
+    do {                                                                    \
+        MI_HIP(hipGetLastError());                                          \
+        if (mi::g_post_launch_hook) mi::g_post_launch_hook((void *)st);     \
+    } while (0)
 
 #define MI_REQUIRE(cond, ...)                                  \
     do {                                                       \
@@ -41,6 +51,11 @@ static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b)
 // exact GELU, F.gelu default (erf form)
 __device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// packed fp32 math: v_pk_fma_f32 issues two IEEE fmas per lane per instruction (same results as two fmaf)
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2f splat2(float x) { return (v2f){x, x}; }
 
 // number of partial-sum slots per statistics row (spreads fp64 atomics over addresses)
 constexpr int kStatSlots = 32;

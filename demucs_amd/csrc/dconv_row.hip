@@ -27,14 +27,25 @@ __device__ __forceinline__ float2 ld2(const float *p, bool ok) {
     return ok ? *reinterpret_cast<const float2 *>(p) : make_float2(0.f, 0.f);
 }
 
+constexpr int kGramPad = 96;        // doubles per wave for the reduced Gram entries (H (H + 1) / 2 + H <= 90)
+// slot of the n-th entry in the enumeration (i, k = i .. H) used by dconv_row_layer: k < H -> upper-triangle entry
+// (row-major), k == H -> NQ + i
+__device__ __forceinline__ constexpr int pend_slot(int n, int H) {
+    int i = 0;
+    while (n > H - i) { n -= H - i + 1; ++i; }
+    return n < H - i ? (i * (2 * H - i + 1)) / 2 + n : H * (H + 1) / 2 + i;
+}
+
 // one residual layer on the row: src -> dst (both [C][T] slices with channel stride cs; may alias)
 template <int C, int H, int DIL>
-__device__ __forceinline__ void dconv_row_layer(const DConvRowLayer &L, const float *src, float *dst, size_t cs, int T, float *wsm,
-                                                bool row_ok) {
+__device__ __forceinline__ void dconv_row_layer(const DConvTimeLayer &LT, const float *src, float *dst, size_t cs, int T, float *wsm,
+                                                double *gred, bool row_ok) {
+    const DConvRowLayer &L = LT.w;
     constexpr int HA = (H + 3) / 4 * 4;
+    constexpr int UNR = C >= 96 ? 1 : 2;      // channel-loop unrolling: the wider kernel has no registers to spare
     float *w0s = wsm;                       // [C][3][HA]
-    float *w3s = w0s + C * 3 * HA;          // [2C][HA]
-    float *b3s = w3s + 2 * C * HA;          // [2C]
+    float *w3s = w0s + C * 3 * HA;          // [C][HA][4] = (value w, value w, gate w, gate w): pre-splatted v_pk_fma_f32 operands
+    float *b3s = w3s + 4 * C * HA;          // [2C]
     float *g2ws = b3s + 2 * C, *g2bs = g2ws + 2 * C;   // [2C] each
     float *lss = g2bs + 2 * C;              // [C]
     float *smalls = lss + C;                // b0, g1w, g1b: [HA] each
@@ -43,24 +54,29 @@ __device__ __forceinline__ void dconv_row_layer(const DConvRowLayer &L, const fl
     const int t0 = (lane < nq ? lane : 0) * kNC;
     __syncthreads();                        // previous layer is done with the LDS weights
     for (int i = tid; i < C * 3 * HA; i += 64 * kRowsPerBlock) w0s[i] = L.w0[i];
-    for (int i = tid; i < 2 * C * HA; i += 64 * kRowsPerBlock) w3s[i] = L.w3[i];
+    for (int i = tid; i < 4 * C * HA; i += 64 * kRowsPerBlock) {
+        const int half = (i >> 1) & 1, k = (i >> 2) % HA, c = (i >> 2) / HA;
+        w3s[i] = L.w3[(size_t)(c + half * C) * HA + k];
+    }
     for (int i = tid; i < 2 * C; i += 64 * kRowsPerBlock) { b3s[i] = L.b3[i]; g2ws[i] = L.g2w[i]; g2bs[i] = L.g2b[i]; }
     for (int i = tid; i < C; i += 64 * kRowsPerBlock) lss[i] = L.ls[i];
     if (tid < HA) { smalls[tid] = L.b0[tid]; smalls[HA + tid] = L.g1w[tid]; smalls[2 * HA + tid] = L.g1b[tid]; }
     __syncthreads();
 
-    // ---- dilated conv3: taps cover columns t0-2 .. t0+7, fetched as five float2, one channel ahead ----------
-    float hid[kNC][HA];
+    // ---- dilated conv3: taps cover columns t0-2 .. t0+7, fetched as five float2, one channel ahead; hidden channels
+    //      in pairs: one v_pk_fma_f32 (two IEEE fmas) per tap and pair ---------------------------------------------
+    v2f hid[kNC][HA / 2];
 #pragma unroll
     for (int j = 0; j < kNC; ++j)
 #pragma unroll
-        for (int m = 0; m < HA; ++m) hid[j][m] = smalls[m];
+        for (int m = 0; m < HA / 2; ++m) hid[j][m] = (v2f){smalls[2 * m], smalls[2 * m + 1]};
     const bool has_l = on && t0 >= 2, has_r = on && t0 + kNC + 2 <= T;
     float2 n0 = ld2(src + t0 - 2, has_l), n1 = ld2(src + t0, on), n2 = ld2(src + t0 + 2, on), n3 = ld2(src + t0 + 4, on),
            n4 = ld2(src + t0 + 6, has_r);
-#pragma unroll 2
+#pragma unroll UNR
     for (int c = 0; c < C; ++c) {
-        const float v[10] = {n0.x, n0.y, n1.x, n1.y, n2.x, n2.y, n3.x, n3.y, n4.x, n4.y};
+        const v2f v[10] = {splat2(n0.x), splat2(n0.y), splat2(n1.x), splat2(n1.y), splat2(n2.x), splat2(n2.y), splat2(n3.x), splat2(n3.y),
+                           splat2(n4.x), splat2(n4.y)};
         if (c + 1 < C) {
             const float *p = src + (c + 1) * cs + t0;
             n0 = ld2(p - 2, has_l); n1 = ld2(p, on); n2 = ld2(p + 2, on); n3 = ld2(p + 4, on); n4 = ld2(p + 6, has_r);
@@ -71,11 +87,9 @@ __device__ __forceinline__ void dconv_row_layer(const DConvRowLayer &L, const fl
             const float4 wa = wv[q], wb = wv[HA / 4 + q], wc = wv[2 * (HA / 4) + q];
 #pragma unroll
             for (int j = 0; j < kNC; ++j) {
-                const float x0 = v[2 + j - DIL], x1 = v[2 + j], x2 = v[2 + j + DIL];
-                hid[j][4 * q + 0] = fmaf(wc.x, x2, fmaf(wb.x, x1, fmaf(wa.x, x0, hid[j][4 * q + 0])));
-                hid[j][4 * q + 1] = fmaf(wc.y, x2, fmaf(wb.y, x1, fmaf(wa.y, x0, hid[j][4 * q + 1])));
-                hid[j][4 * q + 2] = fmaf(wc.z, x2, fmaf(wb.z, x1, fmaf(wa.z, x0, hid[j][4 * q + 2])));
-                hid[j][4 * q + 3] = fmaf(wc.w, x2, fmaf(wb.w, x1, fmaf(wa.w, x0, hid[j][4 * q + 3])));
+                const v2f x0 = v[2 + j - DIL], x1 = v[2 + j], x2 = v[2 + j + DIL];
+                hid[j][2 * q] = fma2((v2f){wc.x, wc.y}, x2, fma2((v2f){wb.x, wb.y}, x1, fma2((v2f){wa.x, wa.y}, x0, hid[j][2 * q])));
+                hid[j][2 * q + 1] = fma2((v2f){wc.z, wc.w}, x2, fma2((v2f){wb.z, wb.w}, x1, fma2((v2f){wa.z, wa.w}, x0, hid[j][2 * q + 1])));
             }
         }
     }
@@ -86,10 +100,11 @@ __device__ __forceinline__ void dconv_row_layer(const DConvRowLayer &L, const fl
 #pragma unroll
         for (int j = 0; j < kNC; ++j)
 #pragma unroll
-            for (int m = 0; m < H; ++m) { p1 += hid[j][m]; p2 += hid[j][m] * hid[j][m]; }
+            for (int m = 0; m < H; ++m) { const float hv = hid[j][m >> 1][m & 1]; p1 += hv; p2 += hv * hv; }
         s1 = p1; s2 = p2;
     }
     wave_sum2(s1, s2);
+    float g[kNC][HA];
     {
         const double cnt = (double)H * T, mean = s1 / cnt;
         const float mu = (float)mean, rs = 1.0f / sqrtf((float)fmax((s2 - s1 * mean) / cnt, 0.0) + 1e-5f);
@@ -97,64 +112,86 @@ __device__ __forceinline__ void dconv_row_layer(const DConvRowLayer &L, const fl
         for (int m = 0; m < HA; ++m) {
             const float gw = smalls[HA + m], gb = smalls[2 * HA + m];
 #pragma unroll
-            for (int j = 0; j < kNC; ++j) hid[j][m] = m < H ? gelu_exact((hid[j][m] - mu) * rs * gw + gb) : 0.f;
+            for (int j = 0; j < kNC; ++j) g[j][m] = (m < H && on) ? gelu_exact((hid[j][m >> 1][m & 1] - mu) * rs * gw + gb) : 0.f;
         }
     }
-    // ---- 1x1 pass A: statistics of z = W3 g + b3 over (2C, T) ------------------------------------------------
-    s1 = 0.0; s2 = 0.0;
+    // ---- statistics of z = W3 g + b3 over (2C, T) WITHOUT evaluating z: with s = sum_t g[t] and G = sum_t g[t] g[t]^T,
+    //      sum z = colsum(W3) . s + T sum(b3),  sum z^2 = <W3^T W3, G> + 2 (W3^T b3) . s + T |b3|^2   (see dconv_time.hip)
+    s1 = (double)T * LT.sum_b3; s2 = (double)T * LT.sum_b3sq;
     {
-        float p1 = 0.f, p2 = 0.f;
-#pragma unroll 2
-        for (int m = 0; m < 2 * C; ++m) {
-            const float4 *wv = reinterpret_cast<const float4 *>(w3s + m * HA);
-            const float bb = b3s[m];
-            float z[kNC];
+        constexpr int NQ = H * (H + 1) / 2, NG = NQ + H;
+        double *gr = gred + (tid >> 6) * kGramPad;            // this wave's reduced Gram entries, then the sums s
+        float pend = 0.f;
+        int idx = 0;
+        // entries are reduced across the wave two at a time (one fp64 butterfly carries both)
 #pragma unroll
-            for (int j = 0; j < kNC; ++j) z[j] = bb;
+        for (int i = 0; i < H; ++i) {
 #pragma unroll
-            for (int q = 0; q < HA / 4; ++q) {
-                const float4 w4 = wv[q];
+            for (int k = i; k <= H; ++k) {                   // k == H: the plain sum of g_i (the vector s)
+                float p = 0.f;
 #pragma unroll
-                for (int j = 0; j < kNC; ++j)
-                    z[j] = fmaf(w4.w, hid[j][4 * q + 3], fmaf(w4.z, hid[j][4 * q + 2], fmaf(w4.y, hid[j][4 * q + 1], fmaf(w4.x, hid[j][4 * q], z[j]))));
+                for (int j = 0; j < kNC; ++j) p = k < H ? fmaf(g[j][i], g[j][k < H ? k : 0], p) : p + g[j][i];
+                const int slot = k < H ? (i * (2 * H - i + 1)) / 2 + (k - i) : NQ + i;
+                if (idx & 1) {
+                    double ra = (double)pend, rb = (double)p;
+                    wave_sum2(ra, rb);
+                    if (lane == 0) { gr[pend_slot(idx - 1, H)] = ra; gr[slot] = rb; }
+                    __builtin_amdgcn_sched_barrier(0);      // one butterfly at a time: interleaving them all would spill
+                } else {
+                    pend = p;
+                }
+                ++idx;
             }
-#pragma unroll
-            for (int j = 0; j < kNC; ++j) { p1 += z[j]; p2 += z[j] * z[j]; }
-            if ((m & 7) == 7) { if (on) { s1 += p1; s2 += p2; } p1 = 0.f; p2 = 0.f; }   // fp32 partials of 48 values
         }
+        if (idx & 1) {
+            double ra = (double)pend, rb = 0.0;
+            wave_sum2(ra, rb);
+            if (lane == 0) gr[pend_slot(idx - 1, H)] = ra;
+        }
+        __syncthreads();                                     // (uniform: every wave of the workgroup runs both layers)
+        double cq = 0.0, cl = 0.0;
+        for (int i = lane; i < NG; i += 64) {
+            const double G = gr[i];
+            if (i < NQ) cq += LT.gram_a[i] * G;
+            else { cq += LT.gram_v[i - NQ] * G; cl += LT.gram_c[i - NQ] * G; }
+        }
+        wave_sum2(cq, cl);
+        s2 += cq; s1 += cl;
     }
-    wave_sum2(s1, s2);
     const double cnt2 = 2.0 * C * T, mean2 = s1 / cnt2;
     const float mu2 = (float)mean2, rs2 = 1.0f / sqrtf((float)fmax((s2 - s1 * mean2) / cnt2, 0.0) + 1e-5f);
-    // ---- 1x1 pass B: GroupNorm + GLU + LayerScale + residual ---------------------------------------------------
+    // ---- 1x1: GroupNorm + GLU + LayerScale + residual; adjacent COLUMNS as packed pairs, weights pre-splatted in LDS ------
+    v2f gp[kNC / 2][HA];
+#pragma unroll
+    for (int jp = 0; jp < kNC / 2; ++jp)
+#pragma unroll
+        for (int m = 0; m < HA; ++m) gp[jp][m] = (v2f){g[2 * jp][m], g[2 * jp + 1][m]};
     float2 r0 = ld2(src + t0, on), r1 = ld2(src + t0 + 2, on), r2 = ld2(src + t0 + 4, on);
-#pragma unroll 2
+#pragma unroll UNR
     for (int c = 0; c < C; ++c) {
         const float r[kNC] = {r0.x, r0.y, r1.x, r1.y, r2.x, r2.y};
         if (c + 1 < C) {
             const float *p = src + (c + 1) * cs + t0;
             r0 = ld2(p, on); r1 = ld2(p + 2, on); r2 = ld2(p + 4, on);
         }
-        const float4 *wa = reinterpret_cast<const float4 *>(w3s + c * HA);
-        const float4 *wg = reinterpret_cast<const float4 *>(w3s + (c + C) * HA);
-        const float ba = b3s[c], bg = b3s[c + C];
-        float za[kNC], zg[kNC];
+        const float4 *wp = reinterpret_cast<const float4 *>(w3s + (size_t)c * HA * 4);
+        v2f zv[kNC / 2], zg[kNC / 2];
 #pragma unroll
-        for (int j = 0; j < kNC; ++j) { za[j] = ba; zg[j] = bg; }
+        for (int jp = 0; jp < kNC / 2; ++jp) { zv[jp] = splat2(b3s[c]); zg[jp] = splat2(b3s[c + C]); }
 #pragma unroll
-        for (int q = 0; q < HA / 4; ++q) {
-            const float4 u = wa[q], w = wg[q];
+        for (int k = 0; k < HA; ++k) {
+            const float4 w = wp[k];                      // (value w, value w, gate w, gate w) of hidden channel k
 #pragma unroll
-            for (int j = 0; j < kNC; ++j) {
-                za[j] = fmaf(u.w, hid[j][4 * q + 3], fmaf(u.z, hid[j][4 * q + 2], fmaf(u.y, hid[j][4 * q + 1], fmaf(u.x, hid[j][4 * q], za[j]))));
-                zg[j] = fmaf(w.w, hid[j][4 * q + 3], fmaf(w.z, hid[j][4 * q + 2], fmaf(w.y, hid[j][4 * q + 1], fmaf(w.x, hid[j][4 * q], zg[j]))));
+            for (int jp = 0; jp < kNC / 2; ++jp) {
+                zv[jp] = fma2((v2f){w.x, w.y}, gp[jp][k], zv[jp]);
+                zg[jp] = fma2((v2f){w.z, w.w}, gp[jp][k], zg[jp]);
             }
         }
         // fold the GroupNorm affine: v = z * A + B
         const float aA = rs2 * g2ws[c], aB = g2bs[c] - mu2 * aA, gA = rs2 * g2ws[c + C], gB = g2bs[c + C] - mu2 * gA, sc = lss[c];
         float o[kNC];
 #pragma unroll
-        for (int j = 0; j < kNC; ++j) o[j] = r[j] + sc * (fmaf(za[j], aA, aB) * sigmoid_f(fmaf(zg[j], gA, gB)));
+        for (int j = 0; j < kNC; ++j) o[j] = r[j] + sc * (fmaf(zv[j >> 1][j & 1], aA, aB) * sigmoid_f(fmaf(zg[j >> 1][j & 1], gA, gB)));
         if (on) {
             float *q = dst + c * cs + t0;
             *reinterpret_cast<float2 *>(q) = make_float2(o[0], o[1]);
@@ -166,16 +203,17 @@ __device__ __forceinline__ void dconv_row_layer(const DConvRowLayer &L, const fl
 }
 
 template <int C, int H>
-__global__ __launch_bounds__(64 * kRowsPerBlock) void dconv_row_kernel(const DConvRowArgs a, int rows) {
+__global__ __launch_bounds__(64 * kRowsPerBlock, 2) void dconv_row_kernel(const DConvRowArgs a, int rows) {
     constexpr int HA = (H + 3) / 4 * 4;
-    __shared__ __attribute__((aligned(16))) float wsm[C * 3 * HA + 2 * C * HA + 7 * C + 3 * HA];
+    __shared__ __attribute__((aligned(16))) float wsm[C * 3 * HA + 4 * C * HA + 7 * C + 3 * HA];
+    __shared__ double gred[kRowsPerBlock * kGramPad];
     const int row = blockIdx.x * kRowsPerBlock + (threadIdx.x >> 6);
     const bool row_ok = row < rows;
     const int rr = row_ok ? row : 0, b = rr / a.Fr, fr = rr - b * a.Fr;
     const size_t cs = (size_t)a.Fr * a.T;
     const size_t off = ((size_t)b * C * a.Fr + fr) * a.T;
-    dconv_row_layer<C, H, 1>(a.l[0], a.x + off, a.y + off, cs, a.T, wsm, row_ok);
-    dconv_row_layer<C, H, 2>(a.l[1], a.y + off, a.y + off, cs, a.T, wsm, row_ok);
+    dconv_row_layer<C, H, 1>(a.l[0], a.x + off, a.y + off, cs, a.T, wsm, gred, row_ok);
+    dconv_row_layer<C, H, 2>(a.l[1], a.y + off, a.y + off, cs, a.T, wsm, gred, row_ok);
 }
 
 bool dconv_row_supported(int C, int T) { return (C == 48 || C == 96) && T % kNC == 0 && T % 2 == 0 && T / kNC <= 64; }

@@ -43,14 +43,28 @@ struct DConvRowLayer {
     const float *b3, *g2w, *g2b;   // [2C]
     const float *ls;    // [C]         LayerScale
 };
+// a DConv layer's weights plus the constants that give the second GroupNorm's statistics from the Gram matrix of the
+// hidden activations (dconv_time.hip, dconv_row.hip)
+struct DConvTimeLayer {
+    DConvRowLayer w;             // same packing as dconv_row.hip
+    const double *gram_a;        // [H (H + 1) / 2]  (W3^T W3)_ii, then 2 (W3^T W3)_ik for k > i, row-major upper triangle
+    const double *gram_v;        // [H]              2 W3^T b3
+    const double *gram_c;        // [H]              column sums of W3
+    double sum_b3, sum_b3sq;
+};
 struct DConvRowArgs {
-    DConvRowLayer l[2];
+    DConvTimeLayer l[2];
     const float *x;     // [B][C][Fr][T]
     float *y;           // same shape (may alias x)
     int Fr, T;
 };
 bool dconv_row_supported(int C, int T);
 int launch_dconv_row(const DConvRowArgs &a, int C, int rows, hipStream_t st);
+
+// dconv_time.hip: fused DConv layer of the time branch (C = 48 / 96), three streaming passes
+bool dconv_time_supported(int C, int Lp);
+int launch_dconv_time_layer(const DConvTimeLayer &l, int C, int dil, int B, int Lv, int Lp, const float *x, float *y, float *hbuf,
+                            double *stats, double *gram, float2 *st1, float2 *st2, hipStream_t st);
 
 // gemm_conv.hip
 int launch_conv(const mi_conv_desc &d, hipStream_t st);

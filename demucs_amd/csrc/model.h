@@ -30,6 +30,8 @@ struct DConvW {
     DConvLayerW l[2];
     bool has_row = false;          // frequency-branch C = 48 / 96: fused LDS-resident row kernel
     DConvRowLayer row[2];
+    bool has_time = false;         // time-branch C = 48 / 96: fused three-pass VALU kernels (dconv_time.hip)
+    DConvTimeLayer tl[2];
 };
 
 struct EncW {
@@ -82,7 +84,7 @@ struct WorkspacePtrs {
     float *w_tr_x[2][2] = {}, *w_tr_qkv[2] = {}, *w_tr_att[2] = {}, *w_tr_x1[2] = {},
           *w_tr_x2[2] = {}, *w_tr_ffh[2] = {};
     float *w_yspec = nullptr, *w_ytime = nullptr, *w_yt = nullptr, *w_fr = nullptr;
-    double *w_stats = nullptr, *w_stats_t = nullptr;
+    double *w_stats = nullptr, *w_stats_t = nullptr, *w_gram = nullptr;
     float2 *w_st1 = nullptr, *w_st2 = nullptr, *w_st1_t = nullptr, *w_st2_t = nullptr;
     float2 *w_norm_f = nullptr, *w_denorm_f = nullptr, *w_norm_t = nullptr, *w_denorm_t = nullptr;
 };
@@ -90,7 +92,7 @@ struct Workspace : WorkspacePtrs {
     std::string key;
     std::vector<void *> allocs;
     int64_t bytes = 0;
-    size_t stats_bytes = 0;
+    size_t stats_bytes = 0, gram_bytes = 0;
     // a forward that failed half-way may leave the self-cleaning statistics slots (norms.hip) non-zero: the next
     // forward re-zeroes them first instead of silently mis-normalising every later call
     bool dirty = false;

@@ -262,6 +262,8 @@ int Model::make_ktab(const Gather &g, int Kpad, mi_ktab_entry **out) {
 int Model::load_dconv(const WeightTable &wt, const std::string &prefix, int C, int64_t chan_stride, int D2, bool freq, DConvW *dw) {
     const int h = C / 8;
     dw->has_row = freq && dconv_row_supported(C, D2);
+    static const bool no_time = getenv("MI_NO_DCONV_TIME") != nullptr;      // A/B switch: fall back to the implicit-GEMM route
+    dw->has_time = !freq && !no_time && dconv_time_supported(C, D2);
     for (int d = 0; d < 2; ++d) {
         DConvLayerW &l = dw->l[d];
         const std::string p = prefix + ".dconv.layers." + std::to_string(d);
@@ -291,7 +293,7 @@ int Model::load_dconv(const WeightTable &wt, const std::string &prefix, int C, i
         MI_TRY(pack_vec(g2w, 2 * C, l.conv1.Mpad, true, &l.gn2_w));
         MI_TRY(pack_vec(g2b, 2 * C, l.conv1.Mpad, true, &l.gn2_b));
         MI_TRY(pack_vec(ls, C, C, false, &l.ls));
-        if (dw->has_row) {          // packing of dconv_row.hip: hidden index fastest, padded to a multiple of 4
+        if (dw->has_row || dw->has_time) {          // packing of dconv_row.hip / dconv_time.hip: hidden index fastest, padded to a multiple of 4
             const int HA = (h + 3) / 4 * 4;
             std::vector<float> w0r((size_t)C * 3 * HA, 0.f), b0r(HA, 0.f), g1wr(HA, 0.f), g1br(HA, 0.f), w3r((size_t)2 * C * HA, 0.f);
             for (int m = 0; m < h; ++m) {
@@ -307,6 +309,25 @@ int Model::load_dconv(const WeightTable &wt, const std::string &prefix, int C, i
             MI_TRY(pack_vec(b3, 2 * C, 2 * C, false, &p5)); MI_TRY(pack_vec(g2w, 2 * C, 2 * C, false, &p6));
             MI_TRY(pack_vec(g2b, 2 * C, 2 * C, false, &p7));
             dw->row[d] = DConvRowLayer{p0, p1, p2, p3, p4, p5, p6, p7, l.ls};
+            {     // second GroupNorm's statistics from the Gram matrix of the hidden activations (dconv_time.hip, dconv_row.hip)
+                std::vector<double> ga, gv(h, 0.0), gc(h, 0.0);
+                double sb = 0.0, sbq = 0.0;
+                for (int m = 0; m < 2 * C; ++m) { sb += (double)b3[m]; sbq += (double)b3[m] * (double)b3[m]; }
+                for (int i = 0; i < h; ++i) {
+                    for (int k = i; k < h; ++k) {
+                        double a = 0.0;
+                        for (int m = 0; m < 2 * C; ++m) a += (double)w3[(size_t)m * h + i] * (double)w3[(size_t)m * h + k];
+                        ga.push_back(k == i ? a : 2.0 * a);
+                    }
+                    for (int m = 0; m < 2 * C; ++m) {
+                        gv[i] += 2.0 * (double)w3[(size_t)m * h + i] * (double)b3[m];
+                        gc[i] += (double)w3[(size_t)m * h + i];
+                    }
+                }
+                double *da, *dv, *dc;
+                MI_TRY(upload(ga, &da)); MI_TRY(upload(gv, &dv)); MI_TRY(upload(gc, &dc));
+                dw->tl[d] = DConvTimeLayer{dw->row[d], da, dv, dc, sb, sbq};
+            }
         }
     }
     return MI_OK;
@@ -577,6 +598,9 @@ int Model::fill_workspace(Workspace &w) {
     w.stats_bytes = max_rows * kStatSlots * 2 * sizeof(double);
     MI_TRY(dev_alloc((void **)&w.w_stats, w.stats_bytes));
     MI_TRY(dev_alloc((void **)&w.w_stats_t, w.stats_bytes));
+    w.gram_bytes = B * kStatSlots * 96 * sizeof(double);          // dconv_time.hip: kGramMax doubles per slot
+    MI_TRY(dev_alloc((void **)&w.w_gram, w.gram_bytes));
+    MI_HIP(hipMemset(w.w_gram, 0, w.gram_bytes));
     MI_HIP(hipMemset(w.w_stats, 0, w.stats_bytes));      // finalize_stats re-zeroes after each use
     MI_HIP(hipMemset(w.w_stats_t, 0, w.stats_bytes));
     MI_TRY(dev_alloc((void **)&w.w_st1, max_rows * sizeof(float2)));
@@ -631,7 +655,7 @@ int Model::run_dconv(const DConvW &w, int C, const Geo &g, float *x, float *tmp,
     const int64_t P = (int64_t)g.D1 * g.pitch();
     const int rows = g.row_mode ? g.B * g.D1 : g.B;
     if (w.has_row && g.row_mode == 1) {      // both layers in one LDS-resident pass, in place
-        DConvRowArgs a{{w.row[0], w.row[1]}, x, x, g.D1, g.D2};
+        DConvRowArgs a{{w.tl[0], w.tl[1]}, x, x, g.D1, g.D2};
         if (prof.on) {
             Profiler::Pending p{101, prof.get(), prof.get(), 2.0 * 2.0 * (3.0 * C * h + 2.0 * 2 * C * h) * (double)rows * g.D2,
                                 2.0 * 4.0 * C * (double)rows * g.D2};
@@ -643,6 +667,23 @@ int Model::run_dconv(const DConvW &w, int C, const Geo &g, float *x, float *tmp,
             return r;
         }
         return launch_dconv_row(a, C, rows, st);
+    }
+    if (w.has_time && g.row_mode == 0 && g.D1 == 1) {     // time branch, C = 48 / 96: three streaming VALU passes per layer
+        const bool timed = prof.on;
+        Profiler::Pending p{102, nullptr, nullptr, 2.0 * 2.0 * (3.0 * C * h + 2.0 * C * h) * (double)g.B * g.D2,
+                            2.0 * 4.0 * C * (double)g.B * g.D2};
+        if (timed) { p.a = prof.get(); p.b = prof.get(); MI_HIP(hipEventRecord(p.a, st)); }
+        float *s = x, *dd = tmp;
+        for (int dlayer = 0; dlayer < 2; ++dlayer) {
+            MI_TRY(launch_dconv_time_layer(w.tl[dlayer], C, 1 << dlayer, g.B, g.D2, g.pitch(), s, dd, hidden, stats, w_gram, st1, st2, st));
+            std::swap(s, dd);
+        }
+        if (timed) {
+            MI_HIP(hipEventRecord(p.b, st));
+            prof.pending.push_back(p);
+            snprintf(prof.rows[102].name, sizeof(prof.rows[102].name), "dconv_time_kernels");
+        }
+        return MI_OK;   // two layers: result is back in x
     }
     const double cnt_row = g.row_mode ? (double)g.D2 : (double)g.D1 * g.D2;
     float *src = x, *dst = tmp;
@@ -732,6 +773,7 @@ int Model::run_core(const float *mix, const float *mag, int B, hipStream_t st) {
     if (ws->dirty) {
         MI_HIP(hipMemsetAsync(w_stats, 0, ws->stats_bytes, st));
         MI_HIP(hipMemsetAsync(w_stats_t, 0, ws->stats_bytes, st));
+        MI_HIP(hipMemsetAsync(w_gram, 0, ws->gram_bytes, st));
         ws->dirty = false;
     }
     const int r = run_core_impl(mix, mag, B, st);

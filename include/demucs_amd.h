@@ -184,6 +184,10 @@ int mi_gn_gelu(float *x_dev, int32_t B, int32_t C, int32_t C_alloc, int32_t D1, 
 int mi_layernorm_cf(const float *x_dev, int32_t B, int32_t C, int32_t T, const float *w_dev, const float *b_dev,
                     const float *add_dev, float *y_dev, void *stream);
 
+/* Debug aid: `hook(stream)` is called after every kernel launch the library makes (NULL switches it off).  Used by
+ * tools/micro/poison_all.py to interleave a register / LDS poisoning kernel between the engine's kernels. */
+void mi_debug_set_post_launch_hook(void (*hook)(void *stream));
+
 const char *mi_last_error(void);
 /* "demucs_amd <version> gfx950" */
 const char *mi_version(void);
