@@ -135,9 +135,14 @@ def apply_model(model, mix, shifts: int = 1, split: bool = True, overlap: float 
         out /= sum_weight
         return out
     # leaf (apply.py:302-322)
-    valid = int(segment * model.samplerate) if segment is not None else model.segment_length
-    if valid < length:
-        raise ValueError(f"Given length {length} is longer than training length {valid}")
+    if hasattr(model, "segment_length"):        # HTDemucs: pad to int(segment * sr), else to the training length (apply.py:305-308)
+        valid = int(segment * model.samplerate) if segment is not None else model.segment_length
+        if valid < length:
+            raise ValueError(f"Given length {length} is longer than training length {valid}")
+    elif hasattr(model, "valid_length"):
+        valid = model.valid_length(length)
+    else:                                        # HDemucs has no valid_length: the chunk runs at its own length (apply.py:309-310)
+        valid = length
     win = mix if isinstance(mix, Window) else Window(mix)
     padded = win.padded(valid)
     if callback is not None:

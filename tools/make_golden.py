@@ -180,8 +180,72 @@ def autocast_fixture(name: str, cfg: HTDemucsConfig, wseed: int, mix: np.ndarray
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **store)
 
 
+def hsegment_fixture(name: str, hcfg, wseed: int, mix: np.ndarray):
+    """One forward of the reference `HDemucs` (hdemucs_mmi architecture) with per-layer taps."""
+    import_reference()
+    from demucs.hdemucs import HDemucs as RefHDemucs
+    from demucs_amd.hdemucs_weights import hdemucs_schema, synthetic_hdemucs_state_dict
+    store = {"meta/wseed": np.array(wseed), "meta/n_sources": np.array(len(hcfg.sources)), "meta/length": np.array(mix.shape[-1])}
+    sd = synthetic_hdemucs_state_dict(hcfg, wseed)
+    for tag, dtype in (("f32", torch.float32), ("f64", torch.float64)):
+        model = RefHDemucs(sources=list(hcfg.sources))
+        ref_schema = [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
+        assert ref_schema == list(hdemucs_schema(hcfg).items()), "hdemucs_schema differs from the reference's state_dict"
+        model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()}, strict=True)
+        model = model.eval().to(dtype)
+        taps, hooks = {}, []
+
+        def mk(nm, pick=None):
+            def hook(mod, inp, out):
+                taps[nm] = out if pick is None else out[pick]
+            return hook
+        for i in range(6):
+            hooks.append(model.encoder[i].register_forward_hook(mk(f"enc{i}" if i else "enc0_preemb")))
+            hooks.append(model.decoder[i].register_forward_hook(mk(f"dec{i}", 0)))
+        for i in range(5):
+            hooks.append(model.tencoder[i].register_forward_hook(mk(f"tenc{i}")))
+            hooks.append(model.tdecoder[i].register_forward_hook(mk(f"tdec{i}", 0)))
+        x = torch.from_numpy(mix).to(dtype)[None]
+        t0 = time.time()
+        with torch.no_grad():
+            out = model(x)
+        print(f"  {name} {tag}: {time.time() - t0:.1f}s  out rms {out.pow(2).mean().sqrt():.4f}  "
+              + " ".join(f"{k}:{v.pow(2).mean().sqrt():.2f}" for k, v in taps.items() if k.startswith("enc") or k.startswith("dec")))
+        for h in hooks:
+            h.remove()
+        taps["out"] = out
+        for k, v in taps.items():
+            pack(f"{tag}/{k}", sample(v, 16384 if k == "out" else 2048), store)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **store)
+
+
+def happly_fixture(name: str, hcfg, wseed: int, mix: np.ndarray, **kw):
+    """Track-level `apply_model` of the reference around its HDemucs (no valid_length: every chunk runs at its own length)."""
+    ref_apply, _ = import_reference()
+    from demucs.hdemucs import HDemucs as RefHDemucs
+    from demucs_amd.hdemucs_weights import synthetic_hdemucs_state_dict
+    store = {"meta/wseed": np.array(wseed), "meta/length": np.array(mix.shape[-1])}
+    for k, v in kw.items():
+        store[f"meta/kw_{k}"] = np.array(v)
+    sd = synthetic_hdemucs_state_dict(hcfg, wseed)
+    for tag, dtype in (("f32", torch.float32), ("f64", torch.float64)):
+        model = RefHDemucs(sources=list(hcfg.sources))
+        model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()}, strict=True)
+        model = model.eval().to(dtype)
+        events = []
+        x = torch.from_numpy(mix).to(dtype)[None]
+        t0 = time.time()
+        out = ref_apply.apply_model(model, x, callback=lambda d: events.append(dict(d)), **kw)
+        print(f"  {name} {tag}: {time.time() - t0:.1f}s  {len(events)} events, out rms {out.pow(2).mean().sqrt():.4f}")
+        pack(f"{tag}/out", sample(out, 16384), store)
+        if tag == "f32":
+            keys = ["model_idx_in_bag", "shift_idx", "segment_offset", "models", "state"]
+            store["events"] = np.array([[str(e[k]) for k in keys] for e in events])
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **store)
+
+
 def main():
-    global segment_fixture, apply_fixture, separator_fixture, autocast_fixture
+    global segment_fixture, apply_fixture, separator_fixture, autocast_fixture, hsegment_fixture, happly_fixture
     only = set(sys.argv[1:])
     if only:                                   # regenerate just the named fixtures
         seg_all, app_all = segment_fixture, apply_fixture
@@ -189,6 +253,9 @@ def main():
         apply_fixture = lambda n, *a, **k: app_all(n, *a, **k) if n in only else None      # noqa: E731
         ac_all = autocast_fixture
         autocast_fixture = lambda n, *a, **k: ac_all(n, *a, **k) if n in only else None     # noqa: E731
+        hs_all, ha_all = hsegment_fixture, happly_fixture
+        hsegment_fixture = lambda n, *a, **k: hs_all(n, *a, **k) if n in only else None     # noqa: E731
+        happly_fixture = lambda n, *a, **k: ha_all(n, *a, **k) if n in only else None       # noqa: E731
         sep_all = separator_fixture
         separator_fixture = lambda n, *a, **k: sep_all(n, *a, **k) if n in only else None   # noqa: E731
     os.makedirs(OUT, exist_ok=True)
@@ -220,6 +287,12 @@ def main():
     print("autocast (reduced-precision noise floor) fixtures")
     autocast_fixture("autocast_seg_tones_w1", cfg4, 1, synth_mix(7, SL, "tones"))
     autocast_fixture("autocast_seg6_noise_w2", cfg6, 2, synth_mix(11, SL, "noise"))
+    print("hdemucs (hdemucs_mmi architecture) fixtures")
+    from demucs_amd.hdemucs_weights import HDemucsConfig
+    hcfg = HDemucsConfig()
+    hsegment_fixture("hseg_tones_10s_w0", hcfg, 0, synth_mix(21, 441000, "tones"))        # T = 431 frames: two BLSTM chunks per row
+    hsegment_fixture("hseg_noise_odd_w1", hcfg, 1, synth_mix(22, 233731, "noise"))        # odd length: every right-padding path
+    happly_fixture("happly_9s_seg4", hcfg, 0, synth_mix(23, 9 * 44100 + 13, "tones"), shifts=0, split=True, overlap=0.25, segment=4)
     print("separator fixtures")
     # a loud, DC-shifted input so that the mono mean / std normalisation of api.py:267-269 is far from the identity
     separator_fixture("separator_shift1", cfg4, 3, 3.0 * synth_mix(12, int(1.3 * SL), "tones") + 0.2, rseed=11,
