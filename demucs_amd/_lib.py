@@ -44,7 +44,7 @@ class MiConvDesc(C.Structure):
         ("y", C.c_void_p), ("y_bstride", C.c_int64), ("y_cstride", C.c_int64),
         ("stats", C.c_void_p), ("gn_stats", C.c_void_p), ("gn_w", C.c_void_p), ("gn_b", C.c_void_p),
         ("out_len", C.c_int32), ("tile_m", C.c_int32), ("plain", C.c_int32), ("half", C.c_int32),
-        ("o2_valid", C.c_int32), ("ktab_len", C.c_int32), ("sink", C.c_void_p), ("wx", C.c_void_p), ("wh", C.c_void_p),
+        ("o2_valid", C.c_int32), ("ktab_len", C.c_int32), ("sink", C.c_void_p), ("wx", C.c_void_p), ("tr_stride", C.c_int32), ("tr_pad", C.c_int32), ("wh", C.c_void_p),
     ]
 
 
@@ -55,6 +55,11 @@ SIGNATURES = {
     "mi_model_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "mi_model_forward_core": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "mi_model_tap": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.c_void_p]),
+    "mi_hmodel_create": (C.c_int, [C.POINTER(MiConfig), C.POINTER(MiTensorDesc), C.c_size_t, C.POINTER(C.c_void_p)]),
+    "mi_hmodel_destroy": (None, [C.c_void_p]),
+    "mi_hmodel_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "mi_hmodel_tap": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.c_void_p]),
+    "mi_hmodel_device_bytes": (C.c_int64, [C.c_void_p]),
     "mi_profile_begin": (C.c_int, [C.c_void_p]),
     "mi_profile_end": (C.c_int, [C.c_void_p, C.POINTER(MiProfileRow), C.c_int32, C.POINTER(C.c_int32), C.c_void_p]),
     "mi_model_device_bytes": (C.c_int64, [C.c_void_p]),

@@ -32,6 +32,7 @@ import torch
 from torch.nn import functional as F
 
 from . import _lib
+from .hdemucs import HDemucs
 from .htdemucs import HTDemucs
 
 __all__ = ["apply_model", "BagOfModels", "TensorChunk", "tensor_chunk", "center_trim", "DummyPoolExecutor"]
@@ -353,7 +354,7 @@ def _i32(values, device) -> torch.Tensor:
 def _is_engine(model) -> bool:
     if isinstance(model, BagOfModels):
         return all(_is_engine(m) for m in model.models)
-    return isinstance(model, HTDemucs)
+    return isinstance(model, (HTDemucs, HDemucs))
 
 
 def _leaf_valid_length(model: HTDemucs, segment_length: int, segment) -> int:

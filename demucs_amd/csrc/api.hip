@@ -4,6 +4,7 @@
 #include "common.h"
 #include "gemm_conv.h"
 #include "kernels.h"
+#include "hmodel.h"
 #include "model.h"
 
 namespace mi {
@@ -113,6 +114,44 @@ int mi_model_forward_core(void *handle, const float *mix_dev, const float *mag_d
     if (!handle) return set_error(MI_EINVAL, "mi_model_forward_core: null handle");
     return ((Model *)handle)->forward_core(mix_dev, mag_dev, spec_out_dev, time_out_dev, B, (hipStream_t)stream);
 }
+
+// ---- Hybrid Demucs v3 (hdemucs_mmi) handles ------------------------------------------------------------------------
+int mi_hmodel_create(const mi_config *cfg, const mi_tensor_desc *weights, size_t n_weights, void **handle) {
+    if (!cfg || !weights || !handle) return set_error(MI_EINVAL, "mi_hmodel_create: null argument");
+    *handle = nullptr;
+    HModel *m = new (std::nothrow) HModel();
+    if (!m) return set_error(MI_ENOMEM, "mi_hmodel_create: host allocation failed");
+    const int r = m->hinit(*cfg, weights, n_weights);
+    if (r != MI_OK) { delete m; return r; }
+    *handle = m;
+    return MI_OK;
+}
+
+void mi_hmodel_destroy(void *handle) {
+    if (!handle) return;
+    (void)hipDeviceSynchronize();
+    delete (HModel *)handle;
+}
+
+int mi_hmodel_forward(void *handle, const float *mix_dev, float *out_dev, int32_t B, int32_t length, void *stream) {
+    if (!handle) return set_error(MI_EINVAL, "mi_hmodel_forward: null handle");
+    return ((HModel *)handle)->hforward(mix_dev, out_dev, B, length, (hipStream_t)stream);
+}
+
+int mi_hmodel_tap(void *handle, const char *name, float *dst_dev, int32_t B, int64_t *numel_per_item, void *stream) {
+    if (!handle || !name || !numel_per_item) return set_error(MI_EINVAL, "mi_hmodel_tap: null argument");
+    HModel *m = (HModel *)handle;
+    auto it = m->taps.find(name);
+    if (it == m->taps.end()) return set_error(MI_EINVAL, "mi_hmodel_tap: unknown tap '%s'", name);
+    *numel_per_item = it->second.second;
+    if (dst_dev) {
+        MI_REQUIRE(B >= 1 && B <= m->cfg.max_batch, "mi_hmodel_tap: batch %d out of range", B);
+        MI_HIP(hipMemcpyAsync(dst_dev, it->second.first, sizeof(float) * (size_t)B * it->second.second, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    }
+    return MI_OK;
+}
+
+int64_t mi_hmodel_device_bytes(void *handle) { return handle ? ((HModel *)handle)->device_bytes + ((HModel *)handle)->hws_bytes : 0; }
 
 int mi_profile_begin(void *handle) {
     if (!handle) return set_error(MI_EINVAL, "mi_profile_begin: null handle");

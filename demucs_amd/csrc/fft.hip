@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256) void istft_frames_kernel(const float *__restri
 // grid (ceil(L/256), B*S*2)
 __global__ __launch_bounds__(256) void istft_ola_kernel(const float *__restrict__ fr, int T, int L, const float *__restrict__ env,
                                                         const float *__restrict__ xt, const float2 *__restrict__ denorm_t, int S,
-                                                        float *__restrict__ out) {
+                                                        int xt_pitch, float *__restrict__ out) {
     const int n = blockIdx.x * 256 + threadIdx.x;
     if (n >= L) return;
     const int bsc = blockIdx.y, c = bsc & 1, bs = bsc >> 1;
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256) void istft_ola_kernel(const float *__restrict_
     if (xt) {
         const int b = bs / S;
         const float2 d = denorm_t[b];
-        v += xt[(size_t)bsc * L + n] * d.y + d.x;
+        v += xt[(size_t)bsc * xt_pitch + n] * d.y + d.x;
     }
     out[(size_t)bsc * L + n] = v;
 }
@@ -294,13 +294,13 @@ int launch_cac_transpose(const float *zt, int B, int T, const float2 *norm, floa
 }
 
 int launch_istft(const float *y, int B, int S, int L, const float2 *denorm, const float *xt, const float2 *denorm_t,
-                 const FftTables &tb, float *yt, float *fr, float *out, hipStream_t st) {
+                 const FftTables &tb, float *yt, float *fr, float *out, hipStream_t st, int xt_pitch) {
     const int T = ceil_div(L, kHop);
     hipLaunchKernelGGL(spec_transpose_kernel, dim3(ceil_div(T, 32), kBins / 32, B * S * 4), dim3(256), 0, st, y, T, S * 4, denorm, yt);
     MI_CHECK_LAUNCH();
     hipLaunchKernelGGL(istft_frames_kernel, dim3(T, B * S), dim3(256), 0, st, yt, T, tb.window, tb.twiddle, fr);
     MI_CHECK_LAUNCH();
-    hipLaunchKernelGGL(istft_ola_kernel, dim3(ceil_div(L, 256), B * S * 2), dim3(256), 0, st, fr, T, L, tb.envelope, xt, denorm_t, S, out);
+    hipLaunchKernelGGL(istft_ola_kernel, dim3(ceil_div(L, 256), B * S * 2), dim3(256), 0, st, fr, T, L, tb.envelope, xt, denorm_t, S, xt_pitch ? xt_pitch : L, out);
     MI_CHECK_LAUNCH();
     return MI_OK;
 }

@@ -19,7 +19,7 @@ enum mi_epilogue {
     MI_EPI_BIAS_STATS = 2,  /* y = acc + bias, and per-row sum / sum-of-squares -> stats (fp64 atomics) */
     MI_EPI_STATS_ONLY = 3,  /* statistics of (acc + bias) only, nothing stored                          */
     MI_EPI_GN_GLU = 4,      /* y[c] = res + scale[c] * GLU(GroupNorm(acc + bias))  (DConv tail)         */
-    MI_EPI_CONVTR = 5       /* rows (co, phase r): y[co][4*o + r - 2] = [res +] act(acc + bias)         */
+    MI_EPI_CONVTR = 5       /* rows (co, phase r): y[co][s*o + r - pad] = [res +] act(acc + bias), s = tr_stride (default 4), pad = tr_pad */
 };
 
 #define MI_FLAG_GELU 1
@@ -77,6 +77,8 @@ typedef struct mi_conv_desc {
     float *sink;            /* >= 256 floats that out-of-range epilogue stores are diverted to; NULL = library-owned */
     const void *wx;         /* NULL, or the weights as the split-bf16 tile image of mi_conv_pack_split for THIS tile_m:
                                selects the 6-product bf16 MFMA main loop (gemm_x6.hip) for tile_m 64 / 96 / 128     */
+    int32_t tr_stride;      /* CONVTR: 0 (= 4, crop 2: ConvTranspose k = 8, s = 4 with the reference's crop folded in), 4 or 2 */
+    int32_t tr_pad;         /* CONVTR with tr_stride != 0: samples cropped from the front (0 = the un-cropped transposed conv)   */
     const void *wh;         /* `half` != 0: the weights as Wh[ceil(Kpad/32)*4][Mpad][8] bf16 / fp16 (mi_conv_pack_half)           */
 } mi_conv_desc;
 

@@ -140,10 +140,11 @@ __device__ __forceinline__ void conv_epilogue(const mi_conv_desc &d, f32x16 (&ac
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int m = mbase + (r & 3) + 8 * (r >> 2);
-                    const int co = m >> 2, ph = m & 3;
+                    const int lg = d.tr_stride == 2 ? 1 : 2, tpad = d.tr_stride ? d.tr_pad : 2;
+                    const int co = m >> lg, ph = m & ((1 << lg) - 1);
                     float v = acc[a][b][r] + biasr[r];
                     if (d.flags & MI_FLAG_GELU) v = gelu_exact(v);
-                    const int o = 4 * ((d.flags & MI_FLAG_TR_FREQ) ? c.o1 : c.o2) + ph - 2;
+                    const int o = (((d.flags & MI_FLAG_TR_FREQ) ? c.o1 : c.o2) << lg) + ph - tpad;
                     const bool ok = c.valid && m < d.M && o >= 0 && o < d.out_len;
                     const size_t pos = (d.flags & MI_FLAG_TR_FREQ) ? (size_t)o * d.O2 + c.o2 : (size_t)o;
                     const size_t idx = ok ? (size_t)c.b * d.y_bstride + (size_t)co * d.y_cstride + pos : 0;

@@ -1,0 +1,216 @@
+// Kernels of the Hybrid Demucs v3 (`hdemucs_mmi`) path that the htdemucs engine has no counterpart for
+// (reference: demucs/hdemucs.py:92-157,304-335 GroupNorm(4) inside the layers; demucs/demucs.py:20-67 BLSTM with
+// overlapping 200-step chunks; demucs/demucs.py:182-216 LocalState attention).  All float32.
+#include "common.h"
+#include "kernels.h"
+
+namespace mi {
+
+// ---- y[b][c][0:L] (row pitch out_pitch) = (x[b][c][0:L] - mean[b]) * inv[b]; padding columns are zeroed --------------
+__global__ __launch_bounds__(256) void row_affine_pitch_kernel(const float *__restrict__ x, int L, int out_pitch, int C,
+                                                               const float2 *__restrict__ norm, float *__restrict__ y) {
+    const int bc = blockIdx.y, b = bc / C;
+    const float2 nm = norm[b];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < out_pitch; i += gridDim.x * 256)
+        y[(size_t)bc * out_pitch + i] = i < L ? (x[(size_t)bc * L + i] - nm.x) * nm.y : 0.f;
+}
+
+int launch_row_affine_pitch(const float *x, int B, int C, int L, int out_pitch, const float2 *norm, float *y, hipStream_t st) {
+    hipLaunchKernelGGL(row_affine_pitch_kernel, dim3(std::min(1024, ceil_div(out_pitch, 256)), B * C), dim3(256), 0, st, x, L, out_pitch, C, norm, y);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+
+// ---- GroupNorm apply with the activations / gating / residual forms the layers use ---------------------------------
+//   x (B, Cin, in_len) with row pitch in_pitch, statistics per (b, group) with Cin / G channels per group;
+//   y[b][co][p] = res? + scale? * act( n(co, p + off) [* sigmoid(n(co + Cout, p + off)) if glu] ),  p in [0, out_len)
+//   n(c, q) = (x[b][c][q] - mean) * rstd * w[c] + bias[c]
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float *__restrict__ x, int Cin, int G, int in_pitch, int off,
+                                                       const float2 *__restrict__ stats, const float *__restrict__ w,
+                                                       const float *__restrict__ bias, int glu, int gelu,
+                                                       const float *__restrict__ scale, const float *__restrict__ res, int res_pitch,
+                                                       float *__restrict__ y, int Cout, int out_len, int out_pitch) {
+    const int co = blockIdx.y, b = blockIdx.z;
+    const int cg = Cin / G;
+    const float2 sa = stats[b * G + co / cg];
+    const float aA = sa.y * w[co], aB = bias[co] - sa.x * aA;
+    float gA = 0.f, gB = 0.f;
+    if (glu) {
+        const float2 sg = stats[b * G + (co + Cout) / cg];
+        gA = sg.y * w[co + Cout]; gB = bias[co + Cout] - sg.x * gA;
+    }
+    const float *xa = x + ((size_t)b * Cin + co) * in_pitch + off;
+    const float *xg = x + ((size_t)b * Cin + co + Cout) * in_pitch + off;
+    const float sc = scale ? scale[co] : 1.f;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < out_len; p += gridDim.x * 256) {
+        float v = fmaf(xa[p], aA, aB);
+        if (glu) v *= sigmoid_f(fmaf(xg[p], gA, gB));
+        if (gelu) v = gelu_exact(v);
+        v *= sc;
+        if (res) v += res[((size_t)b * Cout + co) * res_pitch + p];
+        y[((size_t)b * Cout + co) * out_pitch + p] = v;
+    }
+}
+
+int launch_gn_apply(const float *x, int B, int Cin, int G, int in_pitch, int off, const float2 *stats, const float *w, const float *bias,
+                    int glu, int gelu, const float *scale, const float *res, int res_pitch, float *y, int Cout, int out_len,
+                    int out_pitch, hipStream_t st) {
+    MI_REQUIRE(Cin % G == 0 && (!glu || Cin == 2 * Cout) && (glu || Cin == Cout), "gn_apply: bad channel counts %d -> %d", Cin, Cout);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(std::max(1, std::min(64, ceil_div(out_len, 256))), Cout, B), dim3(256), 0, st, x, Cin, G, in_pitch, off,
+                       stats, w, bias, glu, gelu, scale, res, res_pitch, y, Cout, out_len, out_pitch);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+
+// ---- BLSTM framing (demucs/utils.py:20-35, demucs/demucs.py:38-44,51-64) ---------------------------------------------
+// x (B, C, T) -> frames (B * F, C, W): frame f = columns [f * S, f * S + W), zero past T
+__global__ __launch_bounds__(256) void unfold_frames_kernel(const float *__restrict__ x, int C, int T, int F, int W, int S,
+                                                            float *__restrict__ fr) {
+    const int n = blockIdx.z, c = blockIdx.y, b = n / F, f = n % F;
+    for (int w = blockIdx.x * 256 + threadIdx.x; w < W; w += gridDim.x * 256) {
+        const int t = f * S + w;
+        fr[((size_t)n * C + c) * W + w] = t < T ? x[((size_t)b * C + c) * T + t] : 0.f;
+    }
+}
+// frames (B * F, C, W) -> y (B, C, T) = skip + the kept part of each frame: frame 0 keeps [0, W - S/2), the last one
+// [S/2, W), the others [S/2, W - S/2); concatenated and cut to T
+__global__ __launch_bounds__(256) void restitch_frames_kernel(const float *__restrict__ fr, int C, int T, int F, int W, int S,
+                                                              const float *__restrict__ skip, float *__restrict__ y) {
+    const int b = blockIdx.z, c = blockIdx.y, lim = S / 2;
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < T; t += gridDim.x * 256) {
+        // output position t lies in frame f at column w: frame 0 covers t in [0, W - lim); frame f >= 1 starts at
+        // (W - lim) + (f - 1) * (W - 2 lim) and maps to w = lim + (t - start)
+        int f, w;
+        if (t < W - lim || F == 1) { f = 0; w = t; }
+        else {
+            const int u = t - (W - lim), per = W - 2 * lim;
+            f = 1 + u / per; w = lim + u % per;
+            if (f > F - 1) { w += (f - (F - 1)) * per; f = F - 1; }      // the last frame keeps everything to its end
+        }
+        const size_t o = ((size_t)b * C + c) * T + t;
+        y[o] = fr[(((size_t)b * F + f) * C + c) * W + w] + (skip ? skip[o] : 0.f);
+    }
+}
+
+int launch_unfold_frames(const float *x, int B, int C, int T, int F, int W, int S, float *fr, hipStream_t st) {
+    hipLaunchKernelGGL(unfold_frames_kernel, dim3(1, C, B * F), dim3(256), 0, st, x, C, T, F, W, S, fr);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+int launch_restitch_frames(const float *fr, int B, int C, int T, int F, int W, int S, const float *skip, float *y, hipStream_t st) {
+    hipLaunchKernelGGL(restitch_frames_kernel, dim3(std::max(1, std::min(16, ceil_div(T, 256))), C, B), dim3(256), 0, st, fr, C, T, F, W, S, skip, y);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+
+// ---- LSTM recurrence (nn.LSTM semantics, zero initial state, gate order i, f, g, o) ------------------------------------
+// gx (N, 2 dirs, 4H, W): W_ih x_t + b_ih + b_hh for every step (a GEMM done before); whhT (2 dirs, H, 4H) = W_hh^T so
+// that the H threads of a workgroup read consecutive gate rows; out (N, 2H, W): forward hidden states in channels
+// [0, H), backward ones in [H, 2H).  One workgroup per (sequence, direction); thread j owns hidden unit j.
+template <int H>
+__global__ __launch_bounds__(H) void lstm_seq_kernel(const float *__restrict__ gx, const float *__restrict__ whhT, int W,
+                                                     float *__restrict__ out) {
+    __shared__ float hs[2][H];
+    const int n = blockIdx.x, dir = blockIdx.y, j = threadIdx.x;
+    const float *g = gx + ((size_t)n * 2 + dir) * 4 * H * W;
+    const float *wt = whhT + (size_t)dir * H * 4 * H;
+    float *o = out + ((size_t)n * 2 * H + dir * H + j) * W;
+    float c = 0.f;
+    hs[0][j] = 0.f;
+    __syncthreads();
+    int cur = 0;
+    for (int s = 0; s < W; ++s) {
+        const int t = dir ? W - 1 - s : s;
+        float ai = g[(size_t)(0 * H + j) * W + t], af = g[(size_t)(1 * H + j) * W + t], ag = g[(size_t)(2 * H + j) * W + t],
+              ao = g[(size_t)(3 * H + j) * W + t];
+#pragma unroll 4
+        for (int k = 0; k < H; ++k) {
+            const float hk = hs[cur][k];
+            const float *r = wt + (size_t)k * 4 * H + j;
+            ai = fmaf(r[0], hk, ai); af = fmaf(r[H], hk, af); ag = fmaf(r[2 * H], hk, ag); ao = fmaf(r[3 * H], hk, ao);
+        }
+        c = sigmoid_f(af) * c + sigmoid_f(ai) * tanhf(ag);
+        const float h = sigmoid_f(ao) * tanhf(c);
+        o[t] = h;
+        hs[cur ^ 1][j] = h;
+        __syncthreads();
+        cur ^= 1;
+    }
+}
+
+int launch_lstm_seq(const float *gx, const float *whhT, int N, int H, int W, float *out, hipStream_t st) {
+    if (H == 192) hipLaunchKernelGGL(lstm_seq_kernel<192>, dim3(N, 2), dim3(192), 0, st, gx, whhT, W, out);
+    else if (H == 384) hipLaunchKernelGGL(lstm_seq_kernel<384>, dim3(N, 2), dim3(384), 0, st, gx, whhT, W, out);
+    else return set_error(MI_EINVAL, "lstm: hidden size %d not instantiated", H);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+
+// ---- LocalState attention (demucs/demucs.py:182-216) ------------------------------------------------------------------
+// qkc (B, 3C + 16, T): rows [0, C) queries, [C, 2C) keys, [2C, 3C) content, [3C, 3C + 16) decay logits (heads x 4).
+// For query s of head h:  score(t) = k_t . q_s / sqrt(dh) - |t - s| * slope_s,  slope_s = sum_f (f + 1) * (sigmoid(d_f) / 2) / 2,
+// score(s) = -100, softmax over t, out[c][s] = sum_t w_t content[c][t].  One thread per query, keys staged in LDS.
+template <int DH>
+__global__ __launch_bounds__(64) void local_attn_kernel(const float *__restrict__ qkc, int C, int T, float *__restrict__ out) {
+    constexpr int KT = 32;
+    __shared__ float ks[KT][DH + 1], cs[KT][DH + 1];
+    const int b = blockIdx.z, h = blockIdx.y, s = blockIdx.x * 64 + threadIdx.x;
+    const int rows = 3 * C + 16;
+    const float *base = qkc + (size_t)b * rows * T;
+    const bool ok = s < T;
+    const int sq = ok ? s : 0;
+    float q[DH], acc[DH];
+    const float isq = 1.0f / sqrtf((float)DH);
+#pragma unroll
+    for (int d = 0; d < DH; ++d) { q[d] = base[(size_t)(h * DH + d) * T + sq] * isq; acc[d] = 0.f; }
+    float slope = 0.f;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) slope += (float)(f + 1) * (sigmoid_f(base[(size_t)(3 * C + h * 4 + f) * T + sq]) * 0.5f);
+    slope *= 0.5f;                                           // / ndecay ** 0.5
+    float m = -INFINITY, l = 0.f;
+    for (int t0 = 0; t0 < T; t0 += KT) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < KT * DH; i += 64) {
+            const int d = i / KT, tt = i % KT, t = t0 + tt;
+            ks[tt][d] = t < T ? base[(size_t)(C + h * DH + d) * T + t] : 0.f;
+            cs[tt][d] = t < T ? base[(size_t)(2 * C + h * DH + d) * T + t] : 0.f;
+        }
+        __syncthreads();
+        const int nt = min(KT, T - t0);
+        for (int tt = 0; tt < nt; ++tt) {
+            const int t = t0 + tt;
+            float sc = 0.f;
+#pragma unroll
+            for (int d = 0; d < DH; ++d) sc = fmaf(ks[tt][d], q[d], sc);
+            sc -= fabsf((float)(t - s)) * slope;
+            if (t == s) sc = -100.f;
+            if (sc > m) {
+                const float a = expf(m - sc);
+                l *= a;
+#pragma unroll
+                for (int d = 0; d < DH; ++d) acc[d] *= a;
+                m = sc;
+            }
+            const float p = expf(sc - m);
+            l += p;
+#pragma unroll
+            for (int d = 0; d < DH; ++d) acc[d] = fmaf(p, cs[tt][d], acc[d]);
+        }
+    }
+    if (ok) {
+        const float inv = 1.0f / l;
+#pragma unroll
+        for (int d = 0; d < DH; ++d) out[((size_t)b * C + h * DH + d) * T + s] = acc[d] * inv;
+    }
+}
+
+int launch_local_attn(const float *qkc, int B, int C, int T, float *out, hipStream_t st) {
+    const dim3 grid(ceil_div(T, 64), 4, B);
+    if (C == 192) hipLaunchKernelGGL(local_attn_kernel<48>, grid, dim3(64), 0, st, qkc, C, T, out);
+    else if (C == 384) hipLaunchKernelGGL(local_attn_kernel<96>, grid, dim3(64), 0, st, qkc, C, T, out);
+    else return set_error(MI_EINVAL, "local_attn: %d channels not instantiated", C);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+
+}  // namespace mi

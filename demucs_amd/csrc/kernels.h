@@ -17,7 +17,7 @@ struct FftTables {
 int launch_stft_frames(const float *mix, int B, int L, const FftTables &tb, float *zt, double *stats, hipStream_t st);
 int launch_cac_transpose(const float *zt, int B, int T, const float2 *norm, float *x, hipStream_t st);
 int launch_istft(const float *y, int B, int S, int L, const float2 *denorm, const float *xt, const float2 *denorm_t,
-                 const FftTables &tb, float *yt, float *fr, float *out, hipStream_t st);
+                 const FftTables &tb, float *yt, float *fr, float *out, hipStream_t st, int xt_pitch = 0 /* row pitch of xt, 0 = L */);
 
 // norms.hip
 int launch_row_stats(const float *x, int rows, int64_t count, int64_t row_stride, double *stats, hipStream_t st);
@@ -77,6 +77,16 @@ int launch_pack_split(const float *wt, int Kpad, int Mpad, int tile_m, void *wx,
 // gemm_half.hip: bf16 / fp16 operand main loop (mi_config.dtype)
 int launch_conv_half(const mi_conv_desc &d, int tile, bool plain, hipStream_t st);
 int launch_pack_half(const float *wt, int Kpad, int Mpad, int dtype, void *wh, hipStream_t st);
+
+// hkernels.hip: the Hybrid Demucs v3 (hdemucs_mmi) path's own kernels
+int launch_row_affine_pitch(const float *x, int B, int C, int L, int out_pitch, const float2 *norm, float *y, hipStream_t st);
+int launch_gn_apply(const float *x, int B, int Cin, int G, int in_pitch, int off, const float2 *stats, const float *w, const float *bias,
+                    int glu, int gelu, const float *scale, const float *res, int res_pitch, float *y, int Cout, int out_len,
+                    int out_pitch, hipStream_t st);
+int launch_unfold_frames(const float *x, int B, int C, int T, int F, int W, int S, float *fr, hipStream_t st);
+int launch_restitch_frames(const float *fr, int B, int C, int T, int F, int W, int S, const float *skip, float *y, hipStream_t st);
+int launch_lstm_seq(const float *gx, const float *whhT, int N, int H, int W, float *out, hipStream_t st);
+int launch_local_attn(const float *qkc, int B, int C, int T, float *out, hipStream_t st);
 
 // attention.hip
 int launch_attention(const float *q, const float *k, const float *v, float *o, int B, int heads, int Tq, int Tk, int64_t q_bs,

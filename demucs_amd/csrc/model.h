@@ -28,6 +28,7 @@ struct DConvLayerW {
 };
 struct DConvW {
     DConvLayerW l[2];
+    int h = 0;                     // hidden channels: C / 8 (htdemucs, dconv_comp 8) or C / 4 (hdemucs, dconv_comp 4)
     bool has_row = false;          // frequency-branch C = 48 / 96: fused LDS-resident row kernel
     DConvRowLayer row[2];
     bool has_time = false;         // time-branch C = 48 / 96: fused three-pass VALU kernels (dconv_time.hip)
@@ -130,18 +131,18 @@ struct Model : WorkspacePtrs {
     int run_core(const float *mix, const float *mag, int B, hipStream_t st);
     int run_core_impl(const float *mix, const float *mag, int B, hipStream_t st);
 
-   private:
+   protected:
     int dev_alloc(void **p, size_t bytes);
     template <typename T> int upload(const std::vector<T> &h, T **dptr);
     int pack_split(PackedConv *pc);
     int pack_half(PackedConv *pc);
     int pack_conv(const float *W, const float *bias, int M, int K, bool glu, PackedConv *pc);
-    int pack_convtr(const float *W, const float *bias, int Cin, int Cout, PackedConv *pc);
+    int pack_convtr(const float *W, const float *bias, int Cin, int Cout, PackedConv *pc, int stride = 4);
     int pack_vec(const float *v, int n, int npad, bool glu, float **out);
     int pack_linear_ln(const float *W, const float *bias, const float *ln_w, const float *ln_b, int M, int K, PackedConv *pc,
                        float **c1);
     int make_ktab(const Gather &g, int Kpad, mi_ktab_entry **out);
-    int load_dconv(const WeightTable &wt, const std::string &prefix, int C, int64_t chan_stride, int D2, bool freq, DConvW *dw);
+    int load_dconv(const WeightTable &wt, const std::string &prefix, int C, int64_t chan_stride, int D2, bool freq, DConvW *dw, int comp = 8);
     int alloc_workspace();
     int fill_workspace(Workspace &w);
     int run_dconv(const DConvW &w, int C, const Geo &g, float *x, float *tmp, float *hidden, double *stats, float2 *st1, float2 *st2,

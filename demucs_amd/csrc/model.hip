@@ -17,6 +17,7 @@
 #include "gemm_conv.h"
 #include "kernels.h"
 #include "model.h"
+#include "model_internal.h"
 
 namespace mi {
 
@@ -128,47 +129,6 @@ int Model::attn(const float *q, const float *k, const float *v, float *o, int B,
 // ------------------------------------------------------------------------------------------------
 // weight lookup and packing
 // ------------------------------------------------------------------------------------------------
-struct WeightTable {
-    std::map<std::string, std::pair<const float *, int64_t>> t;
-    int get(const std::string &name, int64_t numel, const float **out) const {
-        auto it = t.find(name);
-        if (it == t.end()) return set_error(MI_EWEIGHT, "missing tensor '%s'", name.c_str());
-        if (it->second.second != numel)
-            return set_error(MI_EWEIGHT, "tensor '%s' has %lld elements, expected %lld", name.c_str(),
-                             (long long)it->second.second, (long long)numel);
-        *out = it->second.first;
-        return MI_OK;
-    }
-};
-
-static int round_up(int v, int m) { return (v + m - 1) / m * m; }
-
-// geometry of one gather table
-struct Gather {
-    int Cin, K1, K2, dil1, dil2, pad1, pad2;
-    int64_t chan_stride;
-    int D2;
-};
-
-static std::vector<mi_ktab_entry> build_ktab(const Gather &g, int Kpad) {
-    std::vector<mi_ktab_entry> tab(Kpad);
-    const int K = g.Cin * g.K1 * g.K2;
-    for (int k = 0; k < Kpad; ++k) {
-        mi_ktab_entry e;
-        if (k < K) {
-            const int ci = k / (g.K1 * g.K2), r = k % (g.K1 * g.K2), k1 = r / g.K2, k2 = r % g.K2;
-            e.d1 = k1 * g.dil1 - g.pad1;
-            e.d2 = k2 * g.dil2 - g.pad2;
-            e.off = (int32_t)(ci * g.chan_stride + (int64_t)e.d1 * g.D2 + e.d2);
-            e.ci = ci;
-        } else {                       // K padding: never valid (weights are zero there as well)
-            e.d1 = -(1 << 29); e.d2 = -(1 << 29); e.off = 0; e.ci = 0;
-        }
-        tab[k] = e;
-    }
-    return tab;
-}
-
 // Second copy of the packed weights as exact 3-term bf16 tile images: selects the 6-product bf16 MFMA main loop
 // (gemm_x6.hip).  Opt-in (MI_X6=1) this round: the kernels pass every single-process parity test and are ~1.4x faster
 // on the transformer's linear layers, but when several PROCESSES share one GPU their results are intermittently
@@ -211,20 +171,20 @@ int Model::pack_conv(const float *W, const float *bias, int M, int K, bool glu, 
     return pack_split(pc);
 }
 
-// ConvTranspose(k=8, s=4) weights W[Cin][Cout][8] -> 4-phase GEMM: row m = 4*co + r, k = 2*ci + j,
-// tap = r + 4*j (output index 4*q + r - 2 receives input q - j through tap r + 4j).
-int Model::pack_convtr(const float *W, const float *bias, int Cin, int Cout, PackedConv *pc) {
-    const int M = 4 * Cout, K = 2 * Cin;
+// ConvTranspose(k = 2s, stride s) weights W[Cin][Cout][2s] -> s-phase GEMM (s = 4: k = 8; s = 2: k = 4): row m = s*co + r,
+// k = 2*ci + j, tap = r + s*j (output index s*q + r - pad receives input q - j through tap r + s*j).
+int Model::pack_convtr(const float *W, const float *bias, int Cin, int Cout, PackedConv *pc, int stride) {
+    const int M = stride * Cout, K = 2 * Cin, ks = 2 * stride;
     const int tile = conv_pick_tile(M);
     pc->M = M; pc->K = K; pc->Mpad = round_up(M, tile); pc->Kpad = round_up(K, 16); pc->tile = tile;
     std::vector<float> wt((size_t)pc->Kpad * pc->Mpad, 0.f), b(pc->Mpad, 0.f);
     for (int ci = 0; ci < Cin; ++ci)
         for (int co = 0; co < Cout; ++co)
-            for (int r = 0; r < 4; ++r)
+            for (int r = 0; r < stride; ++r)
                 for (int j = 0; j < 2; ++j)
-                    wt[(size_t)(2 * ci + j) * pc->Mpad + 4 * co + r] = W[((size_t)ci * Cout + co) * 8 + r + 4 * j];
+                    wt[(size_t)(2 * ci + j) * pc->Mpad + stride * co + r] = W[((size_t)ci * Cout + co) * ks + r + stride * j];
     for (int co = 0; co < Cout; ++co)
-        for (int r = 0; r < 4; ++r) b[4 * co + r] = bias[co];
+        for (int r = 0; r < stride; ++r) b[stride * co + r] = bias[co];
     MI_TRY(upload(wt, &pc->wt));
     MI_TRY(upload(b, &pc->bias));
     MI_TRY(pack_half(pc));
@@ -259,11 +219,12 @@ int Model::make_ktab(const Gather &g, int Kpad, mi_ktab_entry **out) {
     return upload(build_ktab(g, round_up(Kpad, 32)), out);     // entries past Kpad are "never valid": the K step of 32 of gemm_half.hip
 }
 
-int Model::load_dconv(const WeightTable &wt, const std::string &prefix, int C, int64_t chan_stride, int D2, bool freq, DConvW *dw) {
-    const int h = C / 8;
-    dw->has_row = freq && dconv_row_supported(C, D2);
+int Model::load_dconv(const WeightTable &wt, const std::string &prefix, int C, int64_t chan_stride, int D2, bool freq, DConvW *dw, int comp) {
+    const int h = C / comp;
+    dw->h = h;
+    dw->has_row = comp == 8 && freq && dconv_row_supported(C, D2);
     static const bool no_time = getenv("MI_NO_DCONV_TIME") != nullptr;      // A/B switch: fall back to the implicit-GEMM route
-    dw->has_time = !freq && !no_time && dconv_time_supported(C, D2);
+    dw->has_time = comp == 8 && !freq && !no_time && dconv_time_supported(C, D2);
     for (int d = 0; d < 2; ++d) {
         DConvLayerW &l = dw->l[d];
         const std::string p = prefix + ".dconv.layers." + std::to_string(d);
@@ -630,28 +591,10 @@ static bool debug_sync() {
 // ------------------------------------------------------------------------------------------------
 // layer helpers
 // ------------------------------------------------------------------------------------------------
-struct Geo {          // geometry of one activation tensor family
-    int B, D1, D2;    // batch, rows (freq bins or 1), columns (frames / samples)
-    int row_mode;     // 1: DConv / GroupNorm rows are (b, d1) (frequency branch), 0: b
-    int ld;           // row pitch in floats (>= D2, multiple of 4 when it differs): time-branch rows are padded
-    int pitch() const { return ld ? ld : D2; }
-};
-
-static mi_conv_desc base_desc(const PackedConv &pc, const mi_ktab_entry *ktab, const float *x, int64_t x_bs, const Geo &g) {
-    mi_conv_desc d;
-    memset(&d, 0, sizeof(d));
-    d.wt = pc.wt; d.M = pc.M; d.Mpad = pc.Mpad; d.K = pc.K; d.Kpad = pc.Kpad; d.ktab = ktab; d.bias = pc.bias; d.tile_m = pc.tile; d.wx = pc.wx;
-    d.wh = pc.wh; d.half = pc.wh ? pc.half : 0; d.ktab_len = round_up(pc.Kpad, 32);
-    d.x = x; d.x_bstride = x_bs; d.B = g.B; d.D1 = g.D1; d.D2 = g.D2; d.O1 = g.D1; d.O2 = g.pitch(); d.S1 = 1; d.S2 = 1;
-    d.o2_valid = g.pitch() != g.D2 ? g.D2 : 0;       // enumerate the padded row, mask the padding columns
-    d.row_mode = g.row_mode;
-    return d;
-}
-
 // DConv residual branch, in place on x[b][C][D1][D2] (uses tmp of the same size and hidden of size/8)
 int Model::run_dconv(const DConvW &w, int C, const Geo &g, float *x, float *tmp, float *hidden, double *stats, float2 *st1,
                      float2 *st2, hipStream_t st) {
-    const int h = C / 8, hp = round_up(h, 16);
+    const int h = w.h, hp = round_up(h, 16);
     const int64_t P = (int64_t)g.D1 * g.pitch();
     const int rows = g.row_mode ? g.B * g.D1 : g.B;
     if (w.has_row && g.row_mode == 1) {      // both layers in one LDS-resident pass, in place

@@ -1,0 +1,189 @@
+"""Host-side `HDemucs`: the Hybrid Demucs v3 model object (`hdemucs_mmi` architecture) backed by the gfx950 engine.
+
+Mirrors what `apply_model` / `BagOfModels` / `Separator` use on the reference's `demucs.hdemucs.HDemucs`
+(reference: demucs/hdemucs.py:338-794): attributes `.sources .samplerate .audio_channels .segment`, NO `valid_length`
+(so the leaf hands every chunk over at its own length, demucs/apply.py:309-310), `to`, `eval`, `load_state_dict` /
+`state_dict` with the reference's key schema (395 tensors), and `__call__(mix)` mapping float32 `(B, 2, n)` on a GPU to
+`(B, S, 2, n)` for any n from 32768 samples (0.74 s) up.  One `mi_hmodel_forward` call per forward; no PyTorch
+implementation of the network exists in this package and there is no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from collections import OrderedDict
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from .hdemucs_weights import HDemucsConfig, hdemucs_schema
+
+__all__ = ["HDemucs"]
+
+MIN_LENGTH = 32768           # shorter chunks are refused by the engine (demucs_amd/csrc/hmodel.hip: kMinLength)
+
+
+class HDemucs:
+    COMPUTE_DTYPES = {"f32": 0, "bf16": 1, "f16": 2}
+
+    #: reference keywords that cannot change an eval-mode forward of this architecture
+    _INERT = frozenset(("rescale", "dconv_init", "emb_smooth", "wiener_iters", "end_iters", "wiener_residual", "multi_freqs_depth"))
+    #: reference keywords whose value the engine hard-codes
+    _FIXED = dict(channels_time=None, cac=True, rewrite=True, hybrid=True, hybrid_old=False, multi_freqs=None)
+
+    def __init__(self, sources: List[str], max_batch: int = 1, compute_dtype: str = "f32", **kwargs):
+        cfg = HDemucsConfig(sources=list(sources))
+        for k, v in kwargs.items():
+            if hasattr(cfg, k):
+                setattr(cfg, k, v)
+            elif k in self._INERT:
+                continue
+            elif k in self._FIXED:
+                if not (v == self._FIXED[k] or (k == "multi_freqs" and not v)):
+                    raise ValueError(f"unsupported HDemucs argument {k}={v!r}: the MI355X engine implements {k}={self._FIXED[k]!r}")
+            else:
+                raise ValueError(f"unsupported HDemucs argument {k!r}")
+        cfg.validate()
+        if compute_dtype not in self.COMPUTE_DTYPES:
+            raise ValueError(f"compute_dtype must be one of {sorted(self.COMPUTE_DTYPES)}, got {compute_dtype!r}")
+        self.cfg = cfg
+        self.sources = list(sources)
+        self.samplerate = cfg.samplerate
+        self.audio_channels = cfg.audio_channels
+        self.segment = cfg.segment                  # a bag may raise it (BagOfModels: remote/hdemucs_mmi.yaml sets 44)
+        self.max_batch = int(max_batch)
+        self.compute_dtype = compute_dtype
+        self._schema = hdemucs_schema(cfg)
+        self._state: Optional["OrderedDict[str, np.ndarray]"] = None
+        self._handles: Dict[torch.device, tuple] = {}          # device -> (handle, max_length)
+        self._device: Optional[torch.device] = None
+        self.training = False
+
+    # ---- nn.Module-like surface ---------------------------------------------------------------------------------
+    def load_state_dict(self, state, strict: bool = True):
+        missing = [k for k in self._schema if k not in state]
+        unexpected = [k for k in state if k not in self._schema]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"Error(s) in loading state_dict: missing {missing[:4]}, unexpected {unexpected[:4]}")
+        new: "OrderedDict[str, np.ndarray]" = OrderedDict()
+        for k, shape in self._schema.items():
+            v = state[k]
+            if isinstance(v, torch.Tensor):
+                v = v.detach().to("cpu", torch.float32).numpy()
+            v = np.ascontiguousarray(v, dtype=np.float32)
+            if tuple(v.shape) != tuple(shape):
+                raise RuntimeError(f"size mismatch for {k}: checkpoint {tuple(v.shape)} vs model {tuple(shape)}")
+            new[k] = v
+        self._state = new
+        self._release()
+        return self
+
+    def state_dict(self):
+        if self._state is None:
+            raise RuntimeError("HDemucs has no weights: call load_state_dict first")
+        return OrderedDict((k, torch.from_numpy(v.copy())) for k, v in self._state.items())
+
+    def eval(self):
+        self.training = False
+        return self
+
+    def train(self, mode: bool = True):
+        if mode:
+            raise NotImplementedError("demucs_amd.HDemucs is inference-only")
+        return self
+
+    def parameters(self):
+        yield torch.empty(0, device=self._device or torch.device("cpu"))
+
+    def to(self, device):
+        device = torch.device(device)
+        if device.type == "cuda" and device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        self._device = device          # handles are cached per device (see HTDemucs.to)
+        return self
+
+    # ---- engine handle ------------------------------------------------------------------------------------------
+    def _release(self):
+        handles, self._handles = self._handles, {}
+        for dev, (h, _) in handles.items():
+            with torch.cuda.device(dev):
+                _lib.load().mi_hmodel_destroy(C.c_void_p(h))
+
+    release = _release
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
+
+    def _ensure_handle(self, length: int) -> int:
+        if self._state is None:
+            raise RuntimeError("HDemucs has no weights: call load_state_dict first")
+        if self._device is None or self._device.type != "cuda":
+            raise _lib.EngineError("demucs_amd.HDemucs only runs on a GPU device (MI355X); call .to('cuda'). "
+                                   "There is no CPU implementation in this package.")
+        have = self._handles.get(self._device)
+        if have is not None and have[1] >= length:
+            return have[0]
+        lib = _lib.load()
+        if have is not None:                            # a longer chunk than the workspace was sized for: re-create
+            with torch.cuda.device(self._device):
+                lib.mi_hmodel_destroy(C.c_void_p(have[0]))
+            del self._handles[self._device]
+        max_length = max(int(length), int(float(self.segment) * self.samplerate), MIN_LENGTH)
+        names = list(self._state)
+        descs = (_lib.MiTensorDesc * len(names))()
+        for i, k in enumerate(names):
+            v = self._state[k]
+            descs[i].name = k.encode()
+            descs[i].data = v.ctypes.data
+            descs[i].numel = v.size
+        cfg = _lib.MiConfig(len(self.sources), max_length, self.max_batch, self.COMPUTE_DTYPES[self.compute_dtype])
+        h = C.c_void_p()
+        with torch.cuda.device(self._device):
+            _lib.check(lib.mi_hmodel_create(C.byref(cfg), descs, len(names), C.byref(h)), "mi_hmodel_create")
+        self._handles[self._device] = (h.value, max_length)
+        return h.value
+
+    def device_bytes(self) -> int:
+        have = self._handles.get(self._device)
+        return int(_lib.load().mi_hmodel_device_bytes(C.c_void_p(have[0]))) if have else 0
+
+    def tap(self, name: str, batch: int) -> torch.Tensor:
+        """Copy of an internal activation of the last forward (parity tests), shape (batch, numel)."""
+        lib, n = _lib.load(), C.c_int64()
+        h = C.c_void_p(self._handles[self._device][0])
+        _lib.check(lib.mi_hmodel_tap(h, name.encode(), None, batch, C.byref(n), None), "mi_hmodel_tap")
+        out = torch.empty(batch, n.value, device=self._device, dtype=torch.float32)
+        with torch.cuda.device(self._device):
+            _lib.check(lib.mi_hmodel_tap(h, name.encode(), out.data_ptr(), batch, C.byref(n), C.c_void_p(_lib.current_stream_ptr())),
+                       "mi_hmodel_tap")
+        return out
+
+    # ---- forward --------------------------------------------------------------------------------------------------
+    def __call__(self, mix: torch.Tensor) -> torch.Tensor:
+        """HDemucs.forward in eval mode (hdemucs.py:689-794): float32 (B, 2, n) -> (B, S, 2, n), any n >= 32768."""
+        if mix.dim() != 3 or mix.shape[1] != self.audio_channels:
+            raise ValueError(f"expected (B, {self.audio_channels}, n), got {tuple(mix.shape)}")
+        if mix.dtype != torch.float32:
+            raise TypeError("mix must be float32")
+        B, _, length = mix.shape
+        if length < MIN_LENGTH:
+            raise ValueError(f"demucs_amd.HDemucs needs at least {MIN_LENGTH} samples per forward, got {length} "
+                             "(the reference accepts shorter chunks; this engine does not yet)")
+        handle = self._ensure_handle(length)
+        if mix.device != self._device:
+            raise _lib.EngineError(f"mix is on {mix.device} but the model is on {self._device}")
+        mix = mix.contiguous()
+        out = torch.empty(B, len(self.sources), self.audio_channels, length, device=mix.device, dtype=torch.float32)
+        lib = _lib.load()
+        with torch.cuda.device(self._device):
+            for b0 in range(0, B, self.max_batch):
+                nb = min(self.max_batch, B - b0)
+                _lib.check(lib.mi_hmodel_forward(C.c_void_p(handle), mix[b0:b0 + nb].data_ptr(), out[b0:b0 + nb].data_ptr(), nb, length,
+                                                 C.c_void_p(_lib.current_stream_ptr())), "mi_hmodel_forward")
+        return out
+
+    forward = __call__

@@ -1,0 +1,123 @@
+"""SURVEY 8 a25 on a real MI355X: the Hybrid Demucs v3 engine (`hdemucs_mmi` architecture: BLSTM, LocalState, GroupNorm(4),
+merge layer, decoders from zeros, any input length) against the reference's outputs (tests/golden/hseg_*.npz,
+happly_*.npz made by tools/make_golden.py from the imported `demucs.hdemucs.HDemucs`) and the float64 oracle.
+
+Tolerance: the float32 bar of north_star (<= 1e-4 max-abs on the output, scored against the float64 reference run)."""
+import numpy as np
+import pytest
+import torch
+
+from demucs_amd import apply as P
+from demucs_amd.hdemucs import HDemucs
+from demucs_amd.hdemucs_weights import HDemucsConfig, synthetic_hdemucs_state_dict
+from demucs_amd.synth import synth_mix
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+HSEG = {"hseg_tones_10s_w0": (0, lambda: synth_mix(21, 441000, "tones")),
+        "hseg_noise_odd_w1": (1, lambda: synth_mix(22, 233731, "noise"))}
+
+
+def engine(wseed, max_batch=1, compute_dtype="f32"):
+    cfg = HDemucsConfig()
+    m = HDemucs(cfg.sources, max_batch=max_batch, compute_dtype=compute_dtype)
+    m.load_state_dict(synthetic_hdemucs_state_dict(cfg, wseed))
+    return m.to("cuda").eval()
+
+
+@pytest.mark.parametrize("name", list(HSEG))
+def test_forward_matches_reference_golden(golden, name):
+    wseed, mk = HSEG[name]
+    g = golden(name)
+    m = engine(wseed)
+    mix = torch.from_numpy(mk())[None].cuda()
+    out = m(mix)
+    L = mix.shape[-1]
+    T = -(-L // 1024)
+    lt = [L]
+    for _ in range(5):
+        lt.append(-(-lt[-1] // 4))
+    lp = [-(-v // 4) * 4 for v in lt]
+    ch, fr = [48, 96, 192, 384], [512, 128, 32, 8]
+    worst = {}
+    for i in range(4):
+        t = m.tap(f"enc{i}", 1).reshape(1, ch[i], fr[i], T)
+        if i == 0:       # the golden hook sees encoder.0 before the frequency embedding is added
+            w = torch.from_numpy(synthetic_hdemucs_state_dict(HDemucsConfig(), wseed)["freq_emb.embedding.weight"]).cuda()
+            worst["enc0"] = g.check("f64", "enc0_preemb", t - (0.2 * (w * 10.0)).t()[None, :, :, None], atol=2e-4, rtol=2e-4)
+        else:
+            worst[f"enc{i}"] = g.check("f64", f"enc{i}", t, atol=2e-4, rtol=2e-4)
+        tt = m.tap(f"tenc{i}", 1).view(1, ch[i], lp[i + 1])[..., :lt[i + 1]]
+        worst[f"tenc{i}"] = g.check("f64", f"tenc{i}", tt, atol=2e-4, rtol=2e-4)
+    worst["tenc4"] = g.check("f64", "tenc4", m.tap("tenc4", 1).view(1, 768, T), atol=2e-4, rtol=2e-4)
+    worst["enc4"] = g.check("f64", "enc4", m.tap("enc4", 1).view(1, 768, 1, T), atol=2e-4, rtol=2e-4)
+    worst["enc5"] = g.check("f64", "enc5", m.tap("enc5", 1).view(1, 1536, -(-T // 2)), atol=2e-4, rtol=2e-4)
+    worst["dec5"] = g.check("f64", "dec5", m.tap("dec5", 1).view(1, 16, 2048, T), atol=2e-4, rtol=2e-4)
+    worst["tdec4"] = g.check("f64", "tdec4", m.tap("tdec4", 1).view(1, 8, lp[0])[..., :L], atol=2e-4, rtol=2e-4)
+    worst["out"] = g.check("f64", "out", out, atol=TOL)
+    g.check("f32", "out", out, atol=TOL)
+    print(name, {k: f"{v:.2e}" for k, v in worst.items()})
+
+
+def test_full_resolution_vs_float64_oracle_and_batching():
+    """Every sample of a batch of 2 against the float64 oracle (4.2 s: three BLSTM chunks at layer 4, none at layer 5);
+    batched == single-item bit for bit."""
+    from demucs_amd.hdemucs_weights import hdemucs_layer_plan
+    from oracle import apply_oracle as A
+    from oracle import hdemucs_oracle as HO
+    cfg = HDemucsConfig()
+    sd = synthetic_hdemucs_state_dict(cfg, 3)
+    m = HDemucs(cfg.sources, max_batch=2)
+    m.load_state_dict(sd)
+    m.to("cuda")
+    L = 185222
+    mix = torch.stack([torch.from_numpy(synth_mix(31, L, "tones")), torch.from_numpy(synth_mix(32, L, "noise"))])
+    out = m(mix.cuda()).cpu()
+    osd = {k: torch.from_numpy(v.copy()).double() for k, v in sd.items()}
+    with torch.no_grad():
+        want = HO.hdemucs_forward(osd, mix.double(), hdemucs_layer_plan(cfg), 4)
+    err = (out.double() - want).abs().max().item()
+    sdr = A.new_sdr(want.float(), out).min().item()
+    print(f"hdemucs full-resolution max-abs {err:.3e}  min SDR {sdr:.1f} dB  (out rms {want.pow(2).mean().sqrt():.3f})")
+    assert err <= TOL and sdr > 80.0
+    single = m(mix[1:].cuda()).cpu()
+    assert torch.equal(single[0], out[1])
+
+
+def test_apply_model_matches_reference(golden):
+    """`apply_model` around the engine with a segment override: chunks of 176 400 samples and a last one of 52 933, each
+    forwarded at its own length (the reference's HDemucs has no valid_length); host mix in, result on the host."""
+    g = golden("happly_10s_seg4")
+    m = engine(int(g.meta("wseed")))
+    kw = {k[len("meta/kw_"):]: g.z[k].item() for k in g.z.files if k.startswith("meta/kw_")}
+    mix = torch.from_numpy(synth_mix(23, 449833, "tones"))[None]
+    events = []
+    out = P.apply_model(m, mix, device="cuda", callback=lambda d: events.append(dict(d)), **kw)
+    assert out.device.type == "cpu" and out.shape == (1, 4, 2, 449833)
+    e64 = g.check("f64", "out", out, atol=TOL)
+    g.check("f32", "out", out, atol=TOL)
+    keys = ["model_idx_in_bag", "shift_idx", "segment_offset", "models", "state"]
+    got = np.array([[str(e[k]) for k in keys] for e in events])
+    assert got.shape == g.z["events"].shape and (got == g.z["events"]).all()
+    print(f"hdemucs apply_model: max-abs vs reference f64 {e64:.2e}")
+
+
+def test_bag_raises_segment_fp16_mode_and_errors():
+    """remote/hdemucs_mmi.yaml: a bag of one model with `segment: 44` (BagOfModels raises the member's segment, apply.py:53-55);
+    BASELINE configs[4]'s fp16 mode on a 50-second track (two chunks: 44 s and the rest); short chunks are refused loudly."""
+    from oracle import apply_oracle as A
+    lo, hi = engine(0, compute_dtype="f16"), engine(0)
+    bag = P.BagOfModels([lo], segment=44)
+    assert lo.segment == 44
+    L = 50 * 44100
+    mix = torch.from_numpy(synth_mix(5, L, "noise"))[None].cuda()
+    out = P.apply_model(bag, mix, shifts=0, overlap=0.25)
+    assert out.shape == (1, 4, 2, L) and bool(torch.isfinite(out).all())
+    ref = P.apply_model(P.BagOfModels([hi], segment=44), mix, shifts=0, overlap=0.25)
+    sdrs = A.new_sdr(ref.cpu(), out.cpu())
+    print(f"hdemucs fp16 mode, 50 s track, 44 s segments: per-source SDR vs the float32 mode {[round(float(v), 1) for v in sdrs.flatten()]} dB")
+    assert float(sdrs.min()) >= 40.0
+    with pytest.raises(ValueError):
+        hi(torch.zeros(1, 2, 1000, device="cuda"))
+    with pytest.raises(RuntimeError):
+        hi.to("cpu")(torch.zeros(1, 2, 40000))

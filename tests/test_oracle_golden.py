@@ -171,11 +171,11 @@ def test_hdemucs_forward_matches_reference(golden, name, tag, dtype, atol):
 
 def test_hdemucs_apply_model_matches_reference(golden):
     """apply_model around HDemucs: no valid_length, so every chunk runs at its own length (the last one shorter)."""
-    g = golden("happly_9s_seg4")
+    g = golden("happly_10s_seg4")
     cfg = HDemucsConfig()
     model = HO.OracleHDemucs(synthetic_hdemucs_state_dict(cfg, int(g.meta("wseed"))), cfg)
     kw = golden_kwargs(g)
-    mix = torch.from_numpy(synth_mix(23, 9 * 44100 + 13, "tones"))[None]
+    mix = torch.from_numpy(synth_mix(23, 449833, "tones"))[None]
     events = []
     out = A.apply_model(model, mix, callback=lambda d: events.append(dict(d)), **kw)
     g.check("f32", "out", out, atol=8e-5, rtol=8e-5)
