@@ -18,11 +18,12 @@ from typing import Union
 
 import torch
 
+from .hdemucs import HDemucs
 from .htdemucs import HTDemucs
 from .weights import REFERENCE_DEFAULTS, check_reference_keyword
 
 #: qualified names of the reference classes a package may name -> engine class that takes the same keywords
-SUPPORTED = {"demucs.htdemucs.HTDemucs": HTDemucs}
+SUPPORTED = {"demucs.htdemucs.HTDemucs": HTDemucs, "demucs.hdemucs.HDemucs": HDemucs}
 
 
 def _stub(qualname: str):
@@ -34,7 +35,7 @@ def _stub(qualname: str):
 
 _STUBS = {q: _stub(q) for q in SUPPORTED}
 #: other reference model classes: recognised so that the error names them instead of failing inside the unpickler
-_KNOWN_UNSUPPORTED = {q: _stub(q) for q in ("demucs.hdemucs.HDemucs", "demucs.demucs.Demucs")}
+_KNOWN_UNSUPPORTED = {q: _stub(q) for q in ("demucs.demucs.Demucs",)}
 
 
 def _qualname(klass) -> str:
@@ -53,7 +54,7 @@ def read_package(path: Union[str, Path]) -> dict:
     return package
 
 
-def load_model(path_or_package, strict: bool = False, max_batch: int = 8) -> HTDemucs:
+def load_model(path_or_package, strict: bool = False, max_batch: int = 8):
     """demucs/states.py:50-80 for the engine: a dict (already loaded) or a path.  Unknown keywords are dropped with the
     reference's warning unless `strict`; architectures the engine does not implement raise ValueError."""
     if isinstance(path_or_package, dict):
@@ -67,6 +68,22 @@ def load_model(path_or_package, strict: bool = False, max_batch: int = 8) -> HTD
         raise ValueError(f"checkpoint class {qual} is not implemented by the MI355X engine (supported: {sorted(SUPPORTED)})")
     klass = SUPPORTED[qual]
     args, kwargs = tuple(package["args"]), dict(package["kwargs"])
+    if len(args) > 1:
+        raise ValueError("checkpoint package passes hyper-parameters positionally; only `sources` may be positional")
+    if klass is HDemucs:
+        # HDemucs: the engine class itself sorts the reference's keywords (config field / inert / fixed value / unknown);
+        # unknown names follow the reference's warn-and-drop rule unless `strict`.  Omitted keywords mean the reference's
+        # defaults, which ARE the hdemucs_mmi architecture the engine implements.
+        known = set(vars(HDemucs(["_"]).cfg)) | HDemucs._INERT | set(HDemucs._FIXED)
+        for key in list(kwargs):
+            if key not in known and key != "sources":
+                if strict:
+                    raise ValueError(f"unknown HDemucs keyword {key!r} in the checkpoint package")
+                warnings.warn("Dropping inexistant parameter " + key)
+                del kwargs[key]
+        model = klass(*args, max_batch=min(max_batch, 16), **kwargs)
+        set_state(model, package["state"])
+        return model
     cfg_fields = set(vars(klass(["_"]).cfg))
     for key in list(kwargs):
         if key in cfg_fields or key == "sources":
@@ -83,8 +100,6 @@ def load_model(path_or_package, strict: bool = False, max_batch: int = 8) -> HTD
             del kwargs[key]
     # keywords the package omits mean the REFERENCE's defaults (segment=10, dconv_mode=1, bottom_channels=0, ...),
     # not the released-model values the engine class defaults to
-    if len(args) > 1:
-        raise ValueError("checkpoint package passes HTDemucs hyper-parameters positionally; only `sources` may be positional")
     for key, default in REFERENCE_DEFAULTS.items():
         kwargs.setdefault(key, default)
     model = klass(*args, max_batch=max_batch, **kwargs)

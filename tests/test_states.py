@@ -67,8 +67,8 @@ def test_strict_rejects_unknown_keywords_and_dict_input_works(fake_reference_mod
 
 def test_other_architectures_and_quantised_states_are_refused(tmp_path, fake_reference_modules):
     path = tmp_path / "hd.th"
-    torch.save(_package(fake_reference_modules["HDemucs"], False), path)
-    with pytest.raises(ValueError, match="demucs.hdemucs.HDemucs"):
+    torch.save({**_package(fake_reference_modules["HTDemucs"], False), "klass": "demucs.demucs.Demucs"}, path)
+    with pytest.raises(ValueError, match="demucs.demucs.Demucs"):
         states.load_model(path)
     pkg = _package(fake_reference_modules["HTDemucs"], False)
     pkg["state"] = {"__quantized": True, "quantized": []}
@@ -141,3 +141,28 @@ def test_known_reference_keywords_load_silently_and_omitted_ones_mean_reference_
     pkg["kwargs"] = {}
     with pytest.raises(ValueError):
         states.load_model(pkg)
+
+
+def test_hdemucs_packages_load_into_the_hdemucs_engine_class(tmp_path, fake_reference_modules):
+    """`hdemucs_mmi` (75fc33f5) is a `demucs.hdemucs.HDemucs` package: the reader builds the HDemucs engine class, keeps the
+    reference's keyword rules (inert / fixed / unknown) and the bag YAML's `segment: 44` raises the member's segment."""
+    from demucs_amd.apply import BagOfModels
+    from demucs_amd.hdemucs import HDemucs
+    from demucs_amd.hdemucs_weights import HDemucsConfig, synthetic_hdemucs_state_dict
+    cfg = HDemucsConfig()
+    state = {k: torch.from_numpy(v).half() for k, v in synthetic_hdemucs_state_dict(cfg, 1).items()}
+    pkg = {"klass": fake_reference_modules["HDemucs"], "args": (list(cfg.sources),),
+           "kwargs": {"channels": 48, "depth": 6, "dconv_init": 1e-3, "hybrid": True, "rescale": 0.1, "made_up": 1}, "state": state}
+    path = tmp_path / "75fc33f5.th"
+    torch.save(pkg, path)
+    (tmp_path / "hdemucs_mmi.yaml").write_text("models: ['75fc33f5']\nsegment: 44\n")
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        bag = states.LocalRepo(tmp_path).get_model("hdemucs_mmi")
+    assert any("made_up" in str(x.message) for x in w)
+    assert isinstance(bag, BagOfModels) and isinstance(bag.models[0], HDemucs) and bag.models[0].segment == 44
+    assert not hasattr(bag.models[0], "valid_length")
+    with pytest.raises(ValueError):
+        states.load_model({**pkg, "kwargs": {"hybrid": False}})
+    with pytest.raises(ValueError):
+        states.load_model({**pkg, "kwargs": {"depth": 5}})

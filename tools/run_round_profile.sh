@@ -1,12 +1,14 @@
 # Round-end GPU evidence (run through gpurun from the repo root):  bash tools/run_round_profile.sh <tag>
-# full GPU suite, bench line, rocprofv3 kernel stats of the same bench command, and the two PMC passes for HBM traffic.
+# full GPU suite, the default bench line, rocprofv3 kernel stats of the bench command, and the two PMC passes for HBM traffic.
 set -o pipefail
-R=$GRAFT_REPO_ROOT; tag=${1:-v5}; O=$R/gpurun_out
-timeout -k 10 900 python -m pytest tests -m gpu -q > $O/tests_$tag.log 2>&1; tail -3 $O/tests_$tag.log
-timeout -k 10 300 python bench.py --steps 10 --warmup 2 > $O/bench_$tag.log 2>&1 && tail -1 $O/bench_$tag.log > $O/bench_$tag.json
+R=$GRAFT_REPO_ROOT; tag=${1:-round2}; O=$R/gpurun_out/$tag; mkdir -p $O
+timeout -k 10 1000 python -m pytest tests -m gpu -q -s > $O/tests.log 2>&1; echo "tests rc $?" >> $O/tests.log; tail -3 $O/tests.log
+timeout -k 10 400 python bench.py --steps 10 --warmup 2 > $O/bench.json 2> $O/bench.err; tail -c 600 $O/bench.json
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $O/prof_$tag -o p --output-format csv -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $O/prof_$tag.log 2>&1
-timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_fetch_$tag -o p --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_fetch_$tag.log 2>&1
-timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pmc_write_$tag -o p --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_write_$tag.log 2>&1
-cd $R && python3 tools/pmc_traffic.py $O/pmc_fetch_$tag $O/pmc_write_$tag $O/traffic_$tag.json | head -8
-ls $O/prof_$tag | head
+BARE="--no-cpu-baseline --no-host-leg --no-fixed-leg --no-modes-leg"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/prof_f32 -o p --output-format csv -- python3 $R/bench.py --steps 5 --warmup 1 $BARE > $O/prof_f32.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/prof_bf16 -o p --output-format csv -- python3 $R/bench.py --dtype bf16 --steps 5 --warmup 1 $BARE > $O/prof_bf16.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_fetch -o p --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 $BARE > $O/pmc_fetch.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pmc_write -o p --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 $BARE > $O/pmc_write.log 2>&1
+cd $R && python3 tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write $O/traffic.json | head -30
+rm -rf $O/pmc_fetch/*/*.db $O/pmc_write/*/*.db 2>/dev/null; du -sh $O
