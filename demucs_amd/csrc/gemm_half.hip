@@ -107,15 +107,24 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_half_kernel(const mi_conv_de
 
     uint4 areg0 = make_uint4(0, 0, 0, 0), areg1 = areg0;
     float breg[16];
+    // PLAIN (1x1 / linear, channel stride P, P % 4 == 0): thread = (column quad q, pair group pg) loads rows 2 pg, 2 pg + 1,
+    // 16 + 2 pg, 17 + 2 pg of the K step as float4 along n (4 VMEM instructions instead of 16 dword loads), packs the two
+    // rows of a pair per column and writes ONE 16-byte word per pair into the pair-interleaved image
+    //     Bq[k octet][pair in octet][BN] (one dword = 2 operand values per column),
+    // from which a fragment is four conflict-free ds_read_b32 (consecutive lanes = consecutive columns).
+    const int pq = tid & 31, pg = tid >> 5;
+    const ColInfo pc = decompose(n0 + 4 * pq, N, P, d.O2, d.O2);
+    const float *pcol = d.x + (size_t)pc.b * d.x_bstride + pc.p;
+    float4 pq4[4];
+    unsigned *Bq = reinterpret_cast<unsigned *>(&Bs[0][0][0]);         // [2 stages][4 octets][4 pairs][BN] dwords
 
 #define MI_LOAD_TILE(kt)                                                                              \
     do {                                                                                              \
         if (PLAIN) {                                                                                  \
-            _Pragma("unroll") for (int j = 0; j < 16; ++j) {                                          \
-                const int c = (kt) * HK + 16 * bh + j;                                                \
-                const bool ok = lc.valid && c < d.K;                                                  \
-                const float v = *(ok ? xcol + (size_t)c * P : d.x);                                   \
-                breg[j] = ok ? v : 0.f;                                                               \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                           \
+                const int c = (kt) * HK + 16 * (i >> 1) + 2 * pg + (i & 1);                           \
+                const bool ok = pc.valid && c < d.K;                                                  \
+                pq4[i] = ok ? *reinterpret_cast<const float4 *>(pcol + (size_t)c * P) : make_float4(0.f, 0.f, 0.f, 0.f); \
             }                                                                                         \
         } else {                                                                                      \
             _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                           \
@@ -134,9 +143,18 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_half_kernel(const mi_conv_de
 
 #define MI_STORE_TILE(buf)                                                                            \
     do {                                                                                              \
-        _Pragma("unroll") for (int h = 0; h < 2; ++h)                                                 \
-            Bs[buf][2 * bh + h][bn] = make_uint4(pack2<HT>(breg[8 * h], breg[8 * h + 1]), pack2<HT>(breg[8 * h + 2], breg[8 * h + 3]), \
-                                                 pack2<HT>(breg[8 * h + 4], breg[8 * h + 5]), pack2<HT>(breg[8 * h + 6], breg[8 * h + 7])); \
+        if (PLAIN) {                                                                                  \
+            _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                           \
+                const int p = 8 * h + pg;                       /* pair index within the K step */    \
+                const float4 lo = pq4[2 * h], hi = pq4[2 * h + 1];                                    \
+                *reinterpret_cast<uint4 *>(Bq + (((buf) * 4 + (p >> 2)) * 4 + (p & 3)) * BN + 4 * pq) = \
+                    make_uint4(pack2<HT>(lo.x, hi.x), pack2<HT>(lo.y, hi.y), pack2<HT>(lo.z, hi.z), pack2<HT>(lo.w, hi.w)); \
+            }                                                                                         \
+        } else {                                                                                      \
+            _Pragma("unroll") for (int h = 0; h < 2; ++h)                                             \
+                Bs[buf][2 * bh + h][bn] = make_uint4(pack2<HT>(breg[8 * h], breg[8 * h + 1]), pack2<HT>(breg[8 * h + 2], breg[8 * h + 3]), \
+                                                     pack2<HT>(breg[8 * h + 4], breg[8 * h + 5]), pack2<HT>(breg[8 * h + 6], breg[8 * h + 7])); \
+        }                                                                                             \
         if (A_SLOTS >= 1 && a_on0) As[buf][ao0][am0] = areg0;                                         \
         if (A_SLOTS >= 2 && a_on1) As[buf][ao1][am1] = areg1;                                         \
     } while (0)
@@ -162,7 +180,14 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_half_kernel(const mi_conv_de
 #pragma unroll
             for (int a = 0; a < TM; ++a) af[s][a] = As[cur][2 * s + lh][(wm * TM + a) * 32 + li];
 #pragma unroll
-            for (int b = 0; b < TN; ++b) bf[s][b] = Bs[cur][2 * s + lh][(wn * TN + b) * 32 + li];
+            for (int b = 0; b < TN; ++b) {
+                if (PLAIN) {
+                    const unsigned *q = Bq + ((cur * 4 + 2 * s + lh) * 4) * BN + (wn * TN + b) * 32 + li;
+                    bf[s][b] = make_uint4(q[0], q[BN], q[2 * BN], q[3 * BN]);
+                } else {
+                    bf[s][b] = Bs[cur][2 * s + lh][(wn * TN + b) * 32 + li];
+                }
+            }
         }
 #pragma unroll
         for (int s = 0; s < 2; ++s)
