@@ -105,8 +105,10 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_half_kernel(const mi_conv_de
     const int i1b = lc.o1 * d.S1, i2b = lc.o2 * d.S2;
     const float *xcol = d.x + (size_t)lc.b * d.x_bstride + (PLAIN ? (size_t)lc.p : (size_t)i1b * d.D2 + i2b);
 
-    uint4 areg0 = make_uint4(0, 0, 0, 0), areg1 = areg0;
-    float breg[16];
+    // TWO register sets: the loads of K steps k+1 and k+2 are both in flight under the MFMAs of step k (the main loop is
+    // latency bound otherwise: one 24 KiB tile per workgroup in flight keeps the L2 at ~10 TB/s and the matrix pipe at 11 %)
+    uint4 areg0 = make_uint4(0, 0, 0, 0), areg1 = areg0;      // weights (L2 resident) and gathered activations: one step ahead
+    float breg[1][16];
     // PLAIN (1x1 / linear, channel stride P, P % 4 == 0): thread = (column quad q, pair group pg) loads rows 2 pg, 2 pg + 1,
     // 16 + 2 pg, 17 + 2 pg of the K step as float4 along n (4 VMEM instructions instead of 16 dword loads), packs the two
     // rows of a pair per column and writes ONE 16-byte word per pair into the pair-interleaved image
@@ -115,16 +117,17 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_half_kernel(const mi_conv_de
     const int pq = tid & 31, pg = tid >> 5;
     const ColInfo pc = decompose(n0 + 4 * pq, N, P, d.O2, d.O2);
     const float *pcol = d.x + (size_t)pc.b * d.x_bstride + pc.p;
-    float4 pq4[4];
+    float pq4[2][4][4];       // plain float arrays: arrays of HIP vector structs are not promoted to registers
     unsigned *Bq = reinterpret_cast<unsigned *>(&Bs[0][0][0]);         // [2 stages][4 octets][4 pairs][BN] dwords
 
-#define MI_LOAD_TILE(kt)                                                                              \
+#define MI_LOAD_TILE(kt, S)                                                                           \
     do {                                                                                              \
         if (PLAIN) {                                                                                  \
             _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                           \
                 const int c = (kt) * HK + 16 * (i >> 1) + 2 * pg + (i & 1);                           \
                 const bool ok = pc.valid && c < d.K;                                                  \
-                pq4[i] = ok ? *reinterpret_cast<const float4 *>(pcol + (size_t)c * P) : make_float4(0.f, 0.f, 0.f, 0.f); \
+                const float4 t4 = *reinterpret_cast<const float4 *>(ok ? pcol + (size_t)c * P : d.sink + 256);          \
+                pq4[S][i][0] = t4.x; pq4[S][i][1] = t4.y; pq4[S][i][2] = t4.z; pq4[S][i][3] = t4.w;                      \
             }                                                                                         \
         } else {                                                                                      \
             _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                           \
@@ -133,27 +136,30 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_half_kernel(const mi_conv_de
                 _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                       \
                     bool ok;                                                                          \
                     const float v = gather_b(d, ke[j], xcol, i1b, i2b, lc.valid, ok);                 \
-                    breg[8 * h + j] = ok ? v : 0.f;                                                   \
+                    breg[0][8 * h + j] = ok ? v : 0.f;                                                \
                 }                                                                                     \
             }                                                                                         \
         }                                                                                             \
-        if (A_SLOTS >= 1) areg0 = ap0[(size_t)(kt) * a_step];                                         \
-        if (A_SLOTS >= 2) areg1 = ap1[(size_t)(kt) * a_step];                                         \
+    } while (0)
+#define MI_LOAD_A(kt)                                                                                 \
+    do {                                                                                              \
+        if (A_SLOTS >= 1) areg0 = ap0[(size_t)(kt) * a_step];                                            \
+        if (A_SLOTS >= 2) areg1 = ap1[(size_t)(kt) * a_step];                                            \
     } while (0)
 
-#define MI_STORE_TILE(buf)                                                                            \
+#define MI_STORE_TILE(buf, S)                                                                         \
     do {                                                                                              \
         if (PLAIN) {                                                                                  \
             _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                           \
                 const int p = 8 * h + pg;                       /* pair index within the K step */    \
-                const float4 lo = pq4[2 * h], hi = pq4[2 * h + 1];                                    \
-                *reinterpret_cast<uint4 *>(Bq + (((buf) * 4 + (p >> 2)) * 4 + (p & 3)) * BN + 4 * pq) = \
-                    make_uint4(pack2<HT>(lo.x, hi.x), pack2<HT>(lo.y, hi.y), pack2<HT>(lo.z, hi.z), pack2<HT>(lo.w, hi.w)); \
+                *reinterpret_cast<uint4 *>(Bq + (((buf) * 4 + (p >> 2)) * 4 + (p & 3)) * BN + 4 * pq) =                   \
+                    make_uint4(pack2<HT>(pq4[S][2 * h][0], pq4[S][2 * h + 1][0]), pack2<HT>(pq4[S][2 * h][1], pq4[S][2 * h + 1][1]), \
+                               pack2<HT>(pq4[S][2 * h][2], pq4[S][2 * h + 1][2]), pack2<HT>(pq4[S][2 * h][3], pq4[S][2 * h + 1][3])); \
             }                                                                                         \
         } else {                                                                                      \
             _Pragma("unroll") for (int h = 0; h < 2; ++h)                                             \
-                Bs[buf][2 * bh + h][bn] = make_uint4(pack2<HT>(breg[8 * h], breg[8 * h + 1]), pack2<HT>(breg[8 * h + 2], breg[8 * h + 3]), \
-                                                     pack2<HT>(breg[8 * h + 4], breg[8 * h + 5]), pack2<HT>(breg[8 * h + 6], breg[8 * h + 7])); \
+                Bs[buf][2 * bh + h][bn] = make_uint4(pack2<HT>(breg[0][8 * h], breg[0][8 * h + 1]), pack2<HT>(breg[0][8 * h + 2], breg[0][8 * h + 3]), \
+                                                     pack2<HT>(breg[0][8 * h + 4], breg[0][8 * h + 5]), pack2<HT>(breg[0][8 * h + 6], breg[0][8 * h + 7])); \
         }                                                                                             \
         if (A_SLOTS >= 1 && a_on0) As[buf][ao0][am0] = areg0;                                         \
         if (A_SLOTS >= 2 && a_on1) As[buf][ao1][am1] = areg1;                                         \
@@ -168,38 +174,52 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_half_kernel(const mi_conv_de
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     const int li = lane & 31, lh = lane >> 5;
-    MI_LOAD_TILE(0);
-    MI_STORE_TILE(0);
+    // one K step on LDS stage `cur`
+#define MI_COMPUTE(cur)                                                                               \
+    do {                                                                                              \
+        uint4 af[2][TM], bf[2][TN];                                                                   \
+        _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                               \
+            _Pragma("unroll") for (int a = 0; a < TM; ++a) af[s][a] = As[cur][2 * s + lh][(wm * TM + a) * 32 + li]; \
+            _Pragma("unroll") for (int b = 0; b < TN; ++b) {                                          \
+                if (PLAIN) {                                                                          \
+                    const unsigned *q = Bq + (((cur) * 4 + 2 * s + lh) * 4) * BN + (wn * TN + b) * 32 + li; \
+                    bf[s][b] = make_uint4(q[0], q[BN], q[2 * BN], q[3 * BN]);                         \
+                } else {                                                                              \
+                    bf[s][b] = Bs[cur][2 * s + lh][(wn * TN + b) * 32 + li];                          \
+                }                                                                                     \
+            }                                                                                         \
+        }                                                                                             \
+        _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                 \
+            _Pragma("unroll") for (int a = 0; a < TM; ++a)                                            \
+                _Pragma("unroll") for (int b = 0; b < TN; ++b) acc[a][b] = mfma16<HT>(af[s][a], bf[s][b], acc[a][b]); \
+    } while (0)
+
+    // PLAIN: activation tiles are fetched TWO K steps ahead: set 1 holds tile k + 1 while set 0 receives tile k + 2, then
+    // set 0 moves into set 1 (16 register moves per step); the gather path and the weights stay one step ahead.
+    MI_LOAD_TILE(0, 0);
+    MI_LOAD_A(0);
+    MI_STORE_TILE(0, 0);
+    if (PLAIN && nk > 1) MI_LOAD_TILE(1, 1);
     __syncthreads();
     int cur = 0;
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) MI_LOAD_TILE(kt + 1);
-        uint4 af[2][TM], bf[2][TN];
+        if (PLAIN) { if (kt + 2 < nk) MI_LOAD_TILE(kt + 2, 0); }
+        else if (kt + 1 < nk) MI_LOAD_TILE(kt + 1, 0);
+        if (kt + 1 < nk) MI_LOAD_A(kt + 1);
+        MI_COMPUTE(cur);
+        if (kt + 1 < nk) { if (PLAIN) MI_STORE_TILE(cur ^ 1, 1); else MI_STORE_TILE(cur ^ 1, 0); }
+        if (PLAIN) {
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int a = 0; a < TM; ++a) af[s][a] = As[cur][2 * s + lh][(wm * TM + a) * 32 + li];
-#pragma unroll
-            for (int b = 0; b < TN; ++b) {
-                if (PLAIN) {
-                    const unsigned *q = Bq + ((cur * 4 + 2 * s + lh) * 4) * BN + (wn * TN + b) * 32 + li;
-                    bf[s][b] = make_uint4(q[0], q[BN], q[2 * BN], q[3 * BN]);
-                } else {
-                    bf[s][b] = Bs[cur][2 * s + lh][(wn * TN + b) * 32 + li];
-                }
-            }
+                for (int e = 0; e < 4; ++e) pq4[1][i][e] = pq4[0][i][e];
         }
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int a = 0; a < TM; ++a)
-#pragma unroll
-                for (int b = 0; b < TN; ++b) acc[a][b] = mfma16<HT>(af[s][a], bf[s][b], acc[a][b]);
-        if (kt + 1 < nk) MI_STORE_TILE(cur ^ 1);
         __syncthreads();
         cur ^= 1;
     }
+#undef MI_COMPUTE
 #undef MI_LOAD_TILE
+#undef MI_LOAD_A
 #undef MI_STORE_TILE
     conv_epilogue<TM, TN, EPI, LFLAGS>(d, acc, m0, n0, wm, wn, N, P, o2v);
 }
