@@ -111,9 +111,9 @@ __device__ __forceinline__ void stage_twiddles(const float2 *tw, float *twr, flo
 // ---------------------------------------------------------------------------------------------
 // STFT: grid (T, B), block 256.  mix (B,2,L) -> zt[b][t][4][2048] + per-item (sum, sumsq) in fp64.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void stft_frames_kernel(const float *__restrict__ mix, int L, int T, const float *__restrict__ window,
-                                                          const float2 *__restrict__ tw, float *__restrict__ zt,
-                                                          double *__restrict__ stats) {
+__global__ __launch_bounds__(256) void stft_frames_kernel(const float *__restrict__ mix, int L, int T, int el, int er,
+                                                          const float *__restrict__ window, const float2 *__restrict__ tw,
+                                                          float *__restrict__ zt, double *__restrict__ stats) {
     __shared__ float re[kLdsN], im[kLdsN], twr[kN / 2], twi[kN / 2];
     __shared__ double red[8];
     const int i = threadIdx.x, t = blockIdx.x, b = blockIdx.y;
@@ -122,18 +122,20 @@ __global__ __launch_bounds__(256) void stft_frames_kernel(const float *__restric
     // frame t of the kept range is frame t+2 of th.stft: padded-signal samples [(t+2)*1024 - 2048, +4096)
     // of x1 = reflect_pad(mix, 1536, 1536 + T*1024 - L)  (htdemucs.py:433-435); the centre padding of
     // th.stft itself never reaches the kept frames.
-    const int L1 = L + 1536 + (1536 + T * kHop - L);
+    // x1 = pad1d(mix, (1536, 1536 + T*1024 - L), "reflect") (htdemucs.py:433-435, hdemucs.py:23-40): when the input is not
+    // longer than the larger padding, pad1d first zero-pads it by (el, er) to L0 = max_pad + 1 samples and reflects the rest
+    const int L0 = L + el + er, shift = 1536 - el;
     cf u[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int p = i + 256 * r;
-        int q = t * kHop + p;                       // index into x1 (always within [0, L1) for kept frames)
-        if (q >= L1) q = 2 * (L1 - 1) - q;          // defensive: th.stft centre reflect
-        int s = q - 1536;
-        if (s < 0) s = -s;
-        if (s >= L) s = 2 * (L - 1) - s;
+        int q = t * kHop + p - shift;               // index into the zero-padded signal x0 (kept frames never reach th.stft's own centre padding)
+        if (q < 0) q = -q;
+        if (q >= L0) q = 2 * (L0 - 1) - q;
+        const int s = q - el;
+        const bool in = s >= 0 && s < L;
         const float w = window[p];
-        u[r] = {w * x0[s], w * x1[s]};
+        u[r] = {in ? w * x0[s] : 0.f, in ? w * x1[s] : 0.f};
     }
     __syncthreads();   // twiddles staged
     stockham_pass<false, 1>(u, i, re, im, twr, twi);
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(256) void stft_frames_kernel(const float *__restric
 // zt[b][t][4][2048] -> x[b][4][2048][T] with optional (v - mean) * inv, 32x32 LDS tiles.
 // grid (ceil(T/32), 2048/32, B*4)
 __global__ __launch_bounds__(256) void cac_transpose_kernel(const float *__restrict__ zt, int T, const float2 *__restrict__ norm,
-                                                            float *__restrict__ x) {
+                                                            float *__restrict__ x, int Tp /* row pitch of x */) {
     __shared__ float tile[32][33];
     const int bc = blockIdx.z, b = bc >> 2, c = bc & 3;
     const int t0 = blockIdx.x * 32, k0 = blockIdx.y * 32;
@@ -183,7 +185,7 @@ __global__ __launch_bounds__(256) void cac_transpose_kernel(const float *__restr
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int k = k0 + ty + 8 * r, t = t0 + tx;
-        if (t < T) x[(((size_t)b * 4 + c) * kBins + k) * T + t] = (tile[tx][ty + 8 * r] - mean) * inv;
+        if (t < T) x[(((size_t)b * 4 + c) * kBins + k) * Tp + t] = (tile[tx][ty + 8 * r] - mean) * inv;
     }
 }
 
@@ -196,7 +198,7 @@ __global__ __launch_bounds__(256) void cac_transpose_kernel(const float *__restr
 // ---------------------------------------------------------------------------------------------
 // grid (ceil(T/32), 2048/32, B*S*4)
 __global__ __launch_bounds__(256) void spec_transpose_kernel(const float *__restrict__ y, int T, int S4, const float2 *__restrict__ denorm,
-                                                             float *__restrict__ yt) {
+                                                             float *__restrict__ yt, int Tp /* row pitch of y */) {
     __shared__ float tile[32][33];
     const int bc = blockIdx.z, b = bc / S4, sc = bc % S4, s = sc >> 2, c = sc & 3;
     const int t0 = blockIdx.x * 32, k0 = blockIdx.y * 32;
@@ -206,7 +208,7 @@ __global__ __launch_bounds__(256) void spec_transpose_kernel(const float *__rest
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int k = k0 + ty + 8 * r, t = t0 + tx;
-        if (t < T) tile[ty + 8 * r][tx] = y[(((size_t)b * S4 + sc) * kBins + k) * T + t] * std + mean;
+        if (t < T) tile[ty + 8 * r][tx] = y[(((size_t)b * S4 + sc) * kBins + k) * Tp + t] * std + mean;
     }
     __syncthreads();
 #pragma unroll
@@ -281,22 +283,26 @@ __global__ __launch_bounds__(256) void istft_ola_kernel(const float *__restrict_
 // ---------------------------------------------------------------------------------------------
 int launch_stft_frames(const float *mix, int B, int L, const FftTables &tb, float *zt, double *stats, hipStream_t st) {
     const int T = ceil_div(L, kHop);
-    MI_REQUIRE(L > 1620, "stft: segment too short for reflect padding (L=%d)", L);
-    hipLaunchKernelGGL(stft_frames_kernel, dim3(T, B), dim3(256), 0, st, mix, L, T, tb.window, tb.twiddle, zt, stats);
+    MI_REQUIRE(L >= 1, "stft: empty input");
+    // pad1d's short-input rule (hdemucs.py:29-36): zero padding before the reflection
+    const int left = 1536, right = 1536 + T * kHop - L, max_pad = std::max(left, right);
+    int el = 0, er = 0;
+    if (L <= max_pad) { const int extra = max_pad - L + 1; er = std::min(right, extra); el = extra - er; }
+    hipLaunchKernelGGL(stft_frames_kernel, dim3(T, B), dim3(256), 0, st, mix, L, T, el, er, tb.window, tb.twiddle, zt, stats);
     MI_CHECK_LAUNCH();
     return MI_OK;
 }
 
-int launch_cac_transpose(const float *zt, int B, int T, const float2 *norm, float *x, hipStream_t st) {
-    hipLaunchKernelGGL(cac_transpose_kernel, dim3(ceil_div(T, 32), kBins / 32, B * 4), dim3(256), 0, st, zt, T, norm, x);
+int launch_cac_transpose(const float *zt, int B, int T, const float2 *norm, float *x, hipStream_t st, int x_pitch) {
+    hipLaunchKernelGGL(cac_transpose_kernel, dim3(ceil_div(T, 32), kBins / 32, B * 4), dim3(256), 0, st, zt, T, norm, x, x_pitch ? x_pitch : T);
     MI_CHECK_LAUNCH();
     return MI_OK;
 }
 
 int launch_istft(const float *y, int B, int S, int L, const float2 *denorm, const float *xt, const float2 *denorm_t,
-                 const FftTables &tb, float *yt, float *fr, float *out, hipStream_t st, int xt_pitch) {
+                 const FftTables &tb, float *yt, float *fr, float *out, hipStream_t st, int xt_pitch, int y_pitch) {
     const int T = ceil_div(L, kHop);
-    hipLaunchKernelGGL(spec_transpose_kernel, dim3(ceil_div(T, 32), kBins / 32, B * S * 4), dim3(256), 0, st, y, T, S * 4, denorm, yt);
+    hipLaunchKernelGGL(spec_transpose_kernel, dim3(ceil_div(T, 32), kBins / 32, B * S * 4), dim3(256), 0, st, y, T, S * 4, denorm, yt, y_pitch ? y_pitch : T);
     MI_CHECK_LAUNCH();
     hipLaunchKernelGGL(istft_frames_kernel, dim3(T, B * S), dim3(256), 0, st, yt, T, tb.window, tb.twiddle, fr);
     MI_CHECK_LAUNCH();

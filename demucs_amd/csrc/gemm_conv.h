@@ -79,6 +79,9 @@ typedef struct mi_conv_desc {
                                selects the 6-product bf16 MFMA main loop (gemm_x6.hip) for tile_m 64 / 96 / 128     */
     int32_t tr_stride;      /* CONVTR: 0 (= 4, crop 2: ConvTranspose k = 8, s = 4 with the reference's crop folded in), 4 or 2 */
     int32_t tr_pad;         /* CONVTR with tr_stride != 0: samples cropped from the front (0 = the un-cropped transposed conv)   */
+    int32_t x_ld;           /* 0, or the row pitch of X along D2 in floats when it differs from D2 (padded frequency-branch rows of
+                               the hdemucs engine: D2 stays the VALID length the gather bounds test against)                   */
+    int32_t x_ld_pad;
     const void *wh;         /* `half` != 0: the weights as Wh[ceil(Kpad/32)*4][Mpad][8] bf16 / fp16 (mi_conv_pack_half)           */
 } mi_conv_desc;
 

@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256, (TM * TN == 4 ? 3 : 4)) void conv_gemm_kernel(
     const int o2v = d.o2_valid ? d.o2_valid : d.O2;
     const ColInfo lc = decompose(n0 + (PLAIN ? (tid & 31) * 4 : (tid & 127)), N, P, d.O2, PLAIN ? d.O2 : o2v);
     const int i1b = lc.o1 * d.S1, i2b = lc.o2 * d.S2;
-    const float *xcol = d.x + (size_t)lc.b * d.x_bstride + (PLAIN ? (size_t)lc.p : (size_t)i1b * d.D2 + i2b);
+    const float *xcol = d.x + (size_t)lc.b * d.x_bstride + (PLAIN ? (size_t)lc.p : (size_t)i1b * (d.x_ld ? d.x_ld : d.D2) + i2b);
     const int prow = tid >> 5;                                   // plain: first row of this thread
     const float *bp0 = lc.valid ? xcol + (size_t)prow * P : d.x; // plain row pointers (channel stride = P)
     const float *bp1 = lc.valid ? xcol + (size_t)(prow + 8) * P : d.x;
@@ -385,7 +385,7 @@ int launch_conv(const mi_conv_desc &din, hipStream_t st) {
     // plain fast path: a 1x1 / linear layer whose gather is the identity
     const int64_t P = (int64_t)d.O1 * d.O2;
     const bool plain = d.plain && d.K == d.Kpad && P % 4 == 0 && d.x_bstride % 4 == 0 && ((uintptr_t)d.x & 15) == 0 &&
-                       d.S1 == 1 && d.S2 == 1 && d.D1 == d.O1 && d.D2 == d.O2;
+                       d.S1 == 1 && d.S2 == 1 && d.D1 == d.O1 && (d.x_ld ? d.x_ld : d.D2) == d.O2;
     if (d.half) return launch_conv_half(d, tile, plain, st);
     static const int x6_mode = getenv("MI_X6_MODE") ? atoi(getenv("MI_X6_MODE")) : 0;   // bisecting: 1 plain only, 2 gather only
     static const int x6_class = getenv("MI_X6_CLASS") ? atoi(getenv("MI_X6_CLASS")) : -1;   // bisecting: one kernel class only

@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_half_kernel(const mi_conv_de
     const int bh = __builtin_amdgcn_readfirstlane(tid >> 7);
     const ColInfo lc = decompose(n0 + bn, N, P, d.O2, PLAIN ? d.O2 : o2v);
     const int i1b = lc.o1 * d.S1, i2b = lc.o2 * d.S2;
-    const float *xcol = d.x + (size_t)lc.b * d.x_bstride + (PLAIN ? (size_t)lc.p : (size_t)i1b * d.D2 + i2b);
+    const float *xcol = d.x + (size_t)lc.b * d.x_bstride + (PLAIN ? (size_t)lc.p : (size_t)i1b * (d.x_ld ? d.x_ld : d.D2) + i2b);
 
     // TWO register sets: the loads of K steps k+1 and k+2 are both in flight under the MFMAs of step k (the main loop is
     // latency bound otherwise: one 24 KiB tile per workgroup in flight keeps the L2 at ~10 TB/s and the matrix pipe at 11 %)

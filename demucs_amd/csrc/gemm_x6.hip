@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_x6_kernel(const mi_conv_desc
     const int bh = __builtin_amdgcn_readfirstlane(tid >> 7);
     const ColInfo lc = decompose(n0 + bn, N, P, d.O2, PLAIN ? d.O2 : o2v);
     const int i1b = lc.o1 * d.S1, i2b = lc.o2 * d.S2;
-    const float *xcol = d.x + (size_t)lc.b * d.x_bstride + (PLAIN ? (size_t)lc.p : (size_t)i1b * d.D2 + i2b);
+    const float *xcol = d.x + (size_t)lc.b * d.x_bstride + (PLAIN ? (size_t)lc.p : (size_t)i1b * (d.x_ld ? d.x_ld : d.D2) + i2b);
     const float *bp = lc.valid ? xcol + (size_t)(8 * bh) * P : d.sink + 256;     // plain: channel stride = P
     const size_t b_row = lc.valid ? (size_t)P : 0, b_step = lc.valid ? (size_t)BK * P : 0;
     float breg[8];

@@ -29,19 +29,20 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float *__restrict__
                                                        const float2 *__restrict__ stats, const float *__restrict__ w,
                                                        const float *__restrict__ bias, int glu, int gelu,
                                                        const float *__restrict__ scale, const float *__restrict__ res, int res_pitch,
-                                                       float *__restrict__ y, int Cout, int out_len, int out_pitch) {
+                                                       float *__restrict__ y, int Cout, int out_len, int out_pitch, int chan_div) {
+    // chan_div > 1: the "channels" here are (channel, row) pairs of a (C, rows, len) tensor; the affine is per real channel
     const int co = blockIdx.y, b = blockIdx.z;
     const int cg = Cin / G;
     const float2 sa = stats[b * G + co / cg];
-    const float aA = sa.y * w[co], aB = bias[co] - sa.x * aA;
+    const float aA = sa.y * w[co / chan_div], aB = bias[co / chan_div] - sa.x * aA;
     float gA = 0.f, gB = 0.f;
     if (glu) {
         const float2 sg = stats[b * G + (co + Cout) / cg];
-        gA = sg.y * w[co + Cout]; gB = bias[co + Cout] - sg.x * gA;
+        gA = sg.y * w[(co + Cout) / chan_div]; gB = bias[(co + Cout) / chan_div] - sg.x * gA;
     }
     const float *xa = x + ((size_t)b * Cin + co) * in_pitch + off;
     const float *xg = x + ((size_t)b * Cin + co + Cout) * in_pitch + off;
-    const float sc = scale ? scale[co] : 1.f;
+    const float sc = scale ? scale[co / chan_div] : 1.f;
     for (int p = blockIdx.x * 256 + threadIdx.x; p < out_len; p += gridDim.x * 256) {
         float v = fmaf(xa[p], aA, aB);
         if (glu) v *= sigmoid_f(fmaf(xg[p], gA, gB));
@@ -54,10 +55,10 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float *__restrict__
 
 int launch_gn_apply(const float *x, int B, int Cin, int G, int in_pitch, int off, const float2 *stats, const float *w, const float *bias,
                     int glu, int gelu, const float *scale, const float *res, int res_pitch, float *y, int Cout, int out_len,
-                    int out_pitch, hipStream_t st) {
+                    int out_pitch, hipStream_t st, int chan_div) {
     MI_REQUIRE(Cin % G == 0 && (!glu || Cin == 2 * Cout) && (glu || Cin == Cout), "gn_apply: bad channel counts %d -> %d", Cin, Cout);
     hipLaunchKernelGGL(gn_apply_kernel, dim3(std::max(1, std::min(64, ceil_div(out_len, 256))), Cout, B), dim3(256), 0, st, x, Cin, G, in_pitch, off,
-                       stats, w, bias, glu, gelu, scale, res, res_pitch, y, Cout, out_len, out_pitch);
+                       stats, w, bias, glu, gelu, scale, res, res_pitch, y, Cout, out_len, out_pitch, chan_div);
     MI_CHECK_LAUNCH();
     return MI_OK;
 }

@@ -26,7 +26,7 @@ struct HDecW {
 };
 
 struct HGeo {                   // everything that depends on the input length
-    int L = 0, T = 0, T5 = 0, Lt[6] = {}, Lp[6] = {};
+    int L = 0, T = 0, Tp = 0, T5 = 0, Lt[6] = {}, Lp[6] = {};    // Tp: row pitch of the frequency-branch tensors (>= 32, multiple of 4)
     std::map<std::string, const mi_ktab_entry *> ktabs;
     DConvW enc_dconv[4], tenc_dconv[4];      // copies of the weights with this geometry's gather tables
 };
@@ -64,7 +64,8 @@ struct HModel : Model {
     int load_norm(const WeightTable &wt, const std::string &name, int C, float **w, float **b);
     int run_deep(HGeo &g, HEncW &e, int C, int Tn, int B, float *x, float *tmp, hipStream_t st);
     int group_norm(const float *x, int B, int C, int G, int in_pitch, int in_len, int off, const float *w, const float *b, int glu, int gelu,
-                   const float *scale, const float *res, int res_pitch, float *y, int Cout, int out_len, int out_pitch, hipStream_t st);
+                   const float *scale, const float *res, int res_pitch, float *y, int Cout, int out_len, int out_pitch, hipStream_t st,
+                   int chan_div = 1);
     int hforward_impl(const float *mix, float *out, int B, int L, hipStream_t st);
 };
 

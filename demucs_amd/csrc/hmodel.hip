@@ -15,7 +15,8 @@
 
 namespace mi {
 
-constexpr int kMinLength = 32768;      // T >= 32 STFT frames: the row-statistics epilogues of the frequency branch need it
+constexpr int kMinLength = 64;         // any chunk `apply_model` can produce in practice; frequency-branch rows carry a pitch >= 32
+                                       // frames (the row-statistics epilogues reduce 32 columns at a time) whatever the frame count
 static const int hFr[5] = {2048, 512, 128, 32, 8};
 static const int hCh[4] = {48, 96, 192, 384};
 
@@ -183,7 +184,7 @@ int HModel::hinit(const mi_config &c, const mi_tensor_desc *weights, size_t n) {
     }
 
     // ---- workspace for max_batch items of Lmax samples -------------------------------------------------------------
-    const size_t B = c.max_batch, T = Tmax, T5 = (T + 1) / 2;
+    const size_t B = c.max_batch, Tx = Tmax, T = std::max<size_t>(32, (Tmax + 3) / 4 * 4), T5 = (Tx + 1) / 2;     // T: padded frame pitch
     int lt[6], lp[6];
     lt[0] = Lmax;
     for (int i = 0; i < 5; ++i) lt[i + 1] = (lt[i] + 3) / 4;
@@ -243,7 +244,7 @@ int HModel::geometry(int L, HGeo **out) {
     if (it == geos.end()) {
         MI_REQUIRE(geos.size() < 64, "too many distinct input lengths for one handle (64 geometries cached)");
         HGeo g;
-        g.L = L; g.T = (L + 1023) / 1024; g.T5 = (g.T + 1) / 2;
+        g.L = L; g.T = (L + 1023) / 1024; g.T5 = (g.T + 1) / 2; g.Tp = std::max(32, round_up(g.T, 4));
         g.Lt[0] = L;
         for (int i = 0; i < 5; ++i) g.Lt[i + 1] = (g.Lt[i] + 3) / 4;
         for (int i = 0; i < 6; ++i) g.Lp[i] = round_up(g.Lt[i], 4);
@@ -251,7 +252,7 @@ int HModel::geometry(int L, HGeo **out) {
         it = geos.emplace(L, g).first;
         HGeo &G = it->second;
         for (int i = 0; i < 4; ++i) {                   // DConv of layers 0-3: this geometry's gather tables
-            const int C = hCh[i], T = G.T;
+            const int C = hCh[i], T = G.Tp;
             for (int br = 0; br < 2; ++br) {
                 DConvW dw = br ? htenc[i].dconv : henc[i].dconv;
                 const int64_t cs = br ? (int64_t)G.Lp[i + 1] : (int64_t)hFr[i + 1] * T;
@@ -276,13 +277,13 @@ int HModel::geometry(int L, HGeo **out) {
 // GroupNorm(G, C) of x (B, C, in_len) [contiguous rows of pitch in_pitch == in_len] + the fused apply of hkernels.hip
 int HModel::group_norm(const float *x, int B, int C, int G, int in_pitch, int in_len, int off, const float *w, const float *b, int glu,
                        int gelu, const float *scale, const float *res, int res_pitch, float *y, int Cout, int out_len, int out_pitch,
-                       hipStream_t st) {
+                       hipStream_t st, int chan_div) {
     MI_REQUIRE(in_pitch == in_len, "group_norm: statistics need contiguous channel rows");
     const int64_t cnt = (int64_t)(C / G) * in_len;
     MI_REQUIRE(B * G <= cfg.max_batch * 512, "group_norm: too many statistic rows");
     MI_TRY(launch_row_stats(x, B * G, cnt, cnt, x_stats, st));
     MI_TRY(launch_finalize_stats(x_stats, B * G, (double)cnt, 1e-5f, 0, x_st1, nullptr, st));
-    return launch_gn_apply(x, B, C, G, in_pitch, off, x_st1, w, b, glu, gelu, scale, res, res_pitch, y, Cout, out_len, out_pitch, st);
+    return launch_gn_apply(x, B, C, G, in_pitch, off, x_st1, w, b, glu, gelu, scale, res, res_pitch, y, Cout, out_len, out_pitch, st, chan_div);
 }
 
 // DConv with BLSTM + LocalState (layers 4, 5): rows are batch items, x (B, C, Tn) contiguous; result back in x
@@ -362,7 +363,7 @@ int HModel::hforward_impl(const float *mix, float *out, int B, int L, hipStream_
     HGeo *gp;
     MI_TRY(geometry(L, &gp));
     HGeo &g = *gp;
-    const int T = g.T, T5 = g.T5;
+    const int T = g.T, T5 = g.T5, Tp = g.Tp;
     const int *Lt = g.Lt, *Lp = g.Lp;
     const mi_ktab_entry *k;
     taps.clear();
@@ -372,7 +373,7 @@ int HModel::hforward_impl(const float *mix, float *out, int B, int L, hipStream_
     MI_TRY(launch_row_affine_pitch(mix, B, 2, L, Lp[0], x_nt, x_t0, st));
     MI_TRY(launch_stft_frames(mix, B, L, fft, x_zt, x_stats, st));
     MI_TRY(launch_finalize_stats(x_stats, B, 4.0 * 2048 * T, 1e-5f, 1, x_nf, x_df, st));
-    MI_TRY(launch_cac_transpose(x_zt, B, T, x_nf, x_0, st));
+    MI_TRY(launch_cac_transpose(x_zt, B, T, x_nf, x_0, st, Tp));
     // ---- encoder layers 0-3, both branches ------------------------------------------------------------------------
     const float *xf = x_0, *xt = x_t0;
     for (int i = 0; i < 4; ++i) {
@@ -394,15 +395,15 @@ int HModel::hforward_impl(const float *mix, float *out, int B, int L, hipStream_
             taps["tenc" + std::to_string(i)] = {x_skip_t[i], C * P};
         }
         {
-            const Geo gin{B, hFr[i], T, 1}, go{B, hFr[i + 1], T, 1};
-            const int64_t Pin = (int64_t)hFr[i] * T, P = (int64_t)hFr[i + 1] * T;
-            MI_TRY(ktab(g, Gather{Cin, 8, 1, 1, 1, 2, 0, Pin, T}, henc[i].conv.Kpad, &k));
+            const Geo gin{B, hFr[i], T, 1, Tp}, go{B, hFr[i + 1], T, 1, Tp};
+            const int64_t Pin = (int64_t)hFr[i] * Tp, P = (int64_t)hFr[i + 1] * Tp;
+            MI_TRY(ktab(g, Gather{Cin, 8, 1, 1, 1, 2, 0, Pin, Tp}, henc[i].conv.Kpad, &k));
             mi_conv_desc d = base_desc(henc[i].conv, k, xf, Cin * Pin, gin);
             d.O1 = hFr[i + 1]; d.S1 = 4; d.epi = MI_EPI_LINEAR; d.flags = MI_FLAG_GELU;
             d.y = x_a; d.y_bstride = C * P; d.y_cstride = P;
             MI_TRY(conv(d, st));
             MI_TRY(run_dconv(g.enc_dconv[i], C, go, x_a, x_b, x_h, x_stats, x_st1, x_st2, st));
-            MI_TRY(ktab(g, Gather{C, 1, 1, 1, 1, 0, 0, P, T}, henc[i].rewrite.Kpad, &k));
+            MI_TRY(ktab(g, Gather{C, 1, 1, 1, 1, 0, 0, P, Tp}, henc[i].rewrite.Kpad, &k));
             mi_conv_desc r = base_desc(henc[i].rewrite, k, x_a, C * P, go);
             r.plain = 1; r.epi = MI_EPI_GLU; r.y = x_skip[i]; r.y_bstride = C * P; r.y_cstride = P;
             if (i == 0) { r.flags = MI_FLAG_EMB; r.emb = freq_emb; }
@@ -418,9 +419,9 @@ int HModel::hforward_impl(const float *mix, float *out, int B, int L, hipStream_
         d.O2 = T; d.o2_valid = 0; d.S2 = 4; d.epi = MI_EPI_LINEAR; d.y = x_inject; d.y_bstride = (int64_t)768 * T; d.y_cstride = T;
         MI_TRY(conv(d, st));
         taps["tenc4"] = {x_inject, (int64_t)768 * T};
-        MI_TRY(ktab(g, Gather{384, 8, 1, 1, 1, 0, 0, (int64_t)8 * T, T}, henc[4].conv.Kpad, &k));
-        mi_conv_desc e = base_desc(henc[4].conv, k, xf, (int64_t)384 * 8 * T, Geo{B, 8, T, 1});
-        e.O1 = 1; e.S1 = 4; e.epi = MI_EPI_LINEAR; e.flags = MI_FLAG_RES; e.res = x_inject;
+        MI_TRY(ktab(g, Gather{384, 8, 1, 1, 1, 0, 0, (int64_t)8 * Tp, Tp}, henc[4].conv.Kpad, &k));
+        mi_conv_desc e = base_desc(henc[4].conv, k, xf, (int64_t)384 * 8 * Tp, Geo{B, 8, T, 1, Tp});
+        e.O1 = 1; e.O2 = T; e.o2_valid = 0; e.S1 = 4; e.epi = MI_EPI_LINEAR; e.flags = MI_FLAG_RES; e.res = x_inject;      // output rows: exact T
         e.y = x_zA; e.y_bstride = (int64_t)768 * T; e.y_cstride = T;
         MI_TRY(conv(e, st));
         MI_TRY(group_norm(x_zA, B, 768, 4, T, T, 0, henc[4].n1w, henc[4].n1b, 0, 1, nullptr, nullptr, 0, x_a4, 768, T, T, st));
@@ -476,8 +477,9 @@ int HModel::hforward_impl(const float *mix, float *out, int B, int L, hipStream_
         t.O1 = 2; t.epi = MI_EPI_CONVTR; t.flags = MI_FLAG_TR_FREQ; t.tr_stride = 4; t.tr_pad = 0; t.out_len = 8;
         t.y = x_zB; t.y_cstride = (int64_t)8 * T; t.y_bstride = (int64_t)384 * 8 * T;
         MI_TRY(conv(t, st));
-        MI_TRY(group_norm(x_zB, B, 384, 4, 8 * T, 8 * T, 0, hdec[1].n2w, hdec[1].n2b, 0, 1, nullptr, x_skip[3], 8 * T, x_dec[1], 384, 8 * T, 8 * T, st));
-        taps["dec1+skip"] = {x_dec[1], (int64_t)384 * 8 * T};
+        // (channel, frequency row) pairs as rows of T frames: the output and the skip carry the padded pitch Tp
+        MI_TRY(group_norm(x_zB, B, 384 * 8, 4, T, T, 0, hdec[1].n2w, hdec[1].n2b, 0, 1, nullptr, x_skip[3], Tp, x_dec[1], 384 * 8, T, Tp, st, 8));
+        taps["dec1+skip"] = {x_dec[1], (int64_t)384 * 8 * Tp};
         const int Lu = 4 * T + 4;                          // un-cropped ConvTranspose1d(k 8, s 4)
         MI_TRY(ktab(g, Gather{768, 1, 2, 1, -1, 0, 0, (int64_t)T, T}, htdec[0].convtr.Kpad, &k));
         mi_conv_desc tt = base_desc(htdec[0].convtr, k, x_pre, (int64_t)768 * T, Geo{B, 1, T, 0});
@@ -492,17 +494,17 @@ int HModel::hforward_impl(const float *mix, float *out, int B, int L, hipStream_
         const int i = 5 - j, C = hCh[i], Fr = hFr[i + 1];
         const bool last = j == 5;
         {
-            const Geo gg{B, Fr, T, 1};
-            const int64_t P = (int64_t)Fr * T;
-            MI_TRY(ktab(g, Gather{C, 3, 3, 1, 1, 1, 1, P, T}, hdec[j].rewrite.Kpad, &k));
+            const Geo gg{B, Fr, T, 1, Tp};
+            const int64_t P = (int64_t)Fr * Tp;
+            MI_TRY(ktab(g, Gather{C, 3, 3, 1, 1, 1, 1, P, Tp}, hdec[j].rewrite.Kpad, &k));
             mi_conv_desc r = base_desc(hdec[j].rewrite, k, x_dec[j - 1], C * P, gg);
             r.epi = MI_EPI_GLU; r.y = x_a; r.y_bstride = C * P; r.y_cstride = P;
             MI_TRY(conv(r, st));
             const int Cout = last ? 4 * S : hCh[i - 1];
-            MI_TRY(ktab(g, Gather{C, 2, 1, -1, 1, 0, 0, P, T}, hdec[j].convtr.Kpad, &k));
+            MI_TRY(ktab(g, Gather{C, 2, 1, -1, 1, 0, 0, P, Tp}, hdec[j].convtr.Kpad, &k));
             mi_conv_desc t = base_desc(hdec[j].convtr, k, x_a, C * P, gg);
             t.O1 = Fr + 1; t.epi = MI_EPI_CONVTR; t.flags = MI_FLAG_TR_FREQ; t.out_len = 4 * Fr;
-            t.y_cstride = (int64_t)4 * Fr * T; t.y_bstride = Cout * t.y_cstride; t.y = x_dec[j];
+            t.y_cstride = (int64_t)4 * Fr * Tp; t.y_bstride = Cout * t.y_cstride; t.y = x_dec[j];
             if (!last) { t.flags |= MI_FLAG_GELU | MI_FLAG_RES; t.res = x_skip[i - 1]; }
             MI_TRY(conv(t, st));
             taps[std::string("dec") + std::to_string(j) + (last ? "" : "+skip")] = {x_dec[j], t.y_bstride};
@@ -525,7 +527,7 @@ int HModel::hforward_impl(const float *mix, float *out, int B, int L, hipStream_
         }
     }
     // ---- de-normalise, iSTFT, add the time branch (hdemucs.py:770-793) -------------------------------------------------
-    return launch_istft(x_dec[5], B, S, L, x_df, x_tdec[4], x_dt, fft, x_yt, x_fr, out, st, Lp[0]);
+    return launch_istft(x_dec[5], B, S, L, x_df, x_tdec[4], x_dt, fft, x_yt, x_fr, out, st, Lp[0], Tp);
 }
 
 }  // namespace mi

@@ -15,9 +15,10 @@ struct FftTables {
 
 // fft.hip
 int launch_stft_frames(const float *mix, int B, int L, const FftTables &tb, float *zt, double *stats, hipStream_t st);
-int launch_cac_transpose(const float *zt, int B, int T, const float2 *norm, float *x, hipStream_t st);
+int launch_cac_transpose(const float *zt, int B, int T, const float2 *norm, float *x, hipStream_t st, int x_pitch = 0 /* 0 = T */);
 int launch_istft(const float *y, int B, int S, int L, const float2 *denorm, const float *xt, const float2 *denorm_t,
-                 const FftTables &tb, float *yt, float *fr, float *out, hipStream_t st, int xt_pitch = 0 /* row pitch of xt, 0 = L */);
+                 const FftTables &tb, float *yt, float *fr, float *out, hipStream_t st, int xt_pitch = 0 /* row pitch of xt, 0 = L */,
+                 int y_pitch = 0 /* row pitch of y along T, 0 = T */);
 
 // norms.hip
 int launch_row_stats(const float *x, int rows, int64_t count, int64_t row_stride, double *stats, hipStream_t st);
@@ -82,7 +83,7 @@ int launch_pack_half(const float *wt, int Kpad, int Mpad, int dtype, void *wh, h
 int launch_row_affine_pitch(const float *x, int B, int C, int L, int out_pitch, const float2 *norm, float *y, hipStream_t st);
 int launch_gn_apply(const float *x, int B, int Cin, int G, int in_pitch, int off, const float2 *stats, const float *w, const float *bias,
                     int glu, int gelu, const float *scale, const float *res, int res_pitch, float *y, int Cout, int out_len,
-                    int out_pitch, hipStream_t st);
+                    int out_pitch, hipStream_t st, int chan_div = 1);
 int launch_unfold_frames(const float *x, int B, int C, int T, int F, int W, int S, float *fr, hipStream_t st);
 int launch_restitch_frames(const float *fr, int B, int C, int T, int F, int W, int S, const float *skip, float *y, hipStream_t st);
 int launch_lstm_seq(const float *gx, const float *whhT, int N, int H, int W, float *out, hipStream_t st);

@@ -67,6 +67,7 @@ static inline mi_conv_desc base_desc(const PackedConv &pc, const mi_ktab_entry *
     d.wh = pc.wh; d.half = pc.wh ? pc.half : 0; d.ktab_len = round_up(pc.Kpad, 32);
     d.x = x; d.x_bstride = x_bs; d.B = g.B; d.D1 = g.D1; d.D2 = g.D2; d.O1 = g.D1; d.O2 = g.pitch(); d.S1 = 1; d.S2 = 1;
     d.o2_valid = g.pitch() != g.D2 ? g.D2 : 0;       // enumerate the padded row, mask the padding columns
+    d.x_ld = g.pitch() != g.D2 ? g.pitch() : 0;        // ... and the gather / plain loaders step rows by the pitch
     d.row_mode = g.row_mode;
     return d;
 }

@@ -79,9 +79,10 @@ int mi_model_forward_core(void *handle, const float *mix_dev, const float *mag_d
 /* ---- Hybrid Demucs v3 (`hdemucs_mmi`: demucs/hdemucs.py:338-794 with the constructor's defaults; BASELINE.json configs[4]).
  *      mi_config.segment_length is the LONGEST input the handle's workspace is sized for (remote/hdemucs_mmi.yaml: 44 s);
  *      every forward names its own length (the reference's HDemucs has no valid_length: demucs/apply.py:309-310 hands it
- *      each chunk as it is): mix_dev (B, 2, length) -> out_dev (B, n_sources, 2, length), 32768 <= length <= segment_length.
+ *      each chunk as it is): mix_dev (B, 2, length) -> out_dev (B, n_sources, 2, length), 64 <= length <= segment_length.
  *      Tap names: "enc0".."enc5", "tenc0".."tenc4", "dec0+skip".."dec4+skip", "dec5", "tdec0+skip".."tdec3+skip", "tdec4"
- *      (decoder outputs are stored with the next layer's skip already added). ------------------------------------------- */
+ *      (decoder outputs are stored with the next layer's skip already added); frequency-branch taps carry a frame pitch of
+ *      max(32, ceil(T / 4) * 4) floats per row. ------------------------------------------- */
 int mi_hmodel_create(const mi_config *cfg, const mi_tensor_desc *weights, size_t n_weights, void **handle);
 void mi_hmodel_destroy(void *handle);
 int mi_hmodel_forward(void *handle, const float *mix_dev, float *out_dev, int32_t B, int32_t length, void *stream);

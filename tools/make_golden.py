@@ -293,6 +293,7 @@ def main():
     hsegment_fixture("hseg_tones_10s_w0", hcfg, 0, synth_mix(21, 441000, "tones"))        # T = 431 frames: two BLSTM chunks per row
     hsegment_fixture("hseg_noise_odd_w1", hcfg, 1, synth_mix(22, 233731, "noise"))        # odd length: every right-padding path
     # 449 833 samples, 4 s segments: chunks of 176 400 samples and a last one of 52 933 (T = 52 frames, odd length)
+    hsegment_fixture("hseg_tiny_w0", hcfg, 0, synth_mix(24, 1500, "tones"))               # 2 frames: pad1d's zero-then-reflect rule
     happly_fixture("happly_10s_seg4", hcfg, 0, synth_mix(23, 449833, "tones"), shifts=0, split=True, overlap=0.25, segment=4)
     print("separator fixtures")
     # a loud, DC-shifted input so that the mono mean / std normalisation of api.py:267-269 is far from the identity
