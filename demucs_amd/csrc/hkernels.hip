@@ -105,44 +105,70 @@ int launch_restitch_frames(const float *fr, int B, int C, int T, int F, int W, i
 }
 
 // ---- LSTM recurrence (nn.LSTM semantics, zero initial state, gate order i, f, g, o) ------------------------------------
-// gx (N, 2 dirs, 4H, W): W_ih x_t + b_ih + b_hh for every step (a GEMM done before); whhT (2 dirs, H, 4H) = W_hh^T so
-// that the H threads of a workgroup read consecutive gate rows; out (N, 2H, W): forward hidden states in channels
-// [0, H), backward ones in [H, 2H).  One workgroup per (sequence, direction); thread j owns hidden unit j.
+// gx (N, 2 dirs, 4H, W): W_ih x_t + b_ih + b_hh for every step (a GEMM done before); whh (2 dirs, 4H, H) = W_hh;
+// out (N, 2H, W): forward hidden states in channels [0, H), backward ones in [H, 2H).
+// ONE LAUNCH PER TIME STEP: the recurrent matrix (2.4 MB per direction at H = 384) cannot stream through one CU per step
+// (a persistent workgroup per sequence ran at 36 us per step), so every step spreads it over (H / 4) x 2 workgroups: a
+// workgroup owns 4 hidden units (their 16 gate rows, held in registers: 24 / 12 weights per thread) of one direction for
+// ALL sequences, reads the previous hidden states (N x H, L2 resident) tile by tile into LDS, reduces the 16 k slices of
+// a row with lane shuffles and applies the gate non-linearities.  The hidden state ping-pongs between two global buffers;
+// the launch boundary is the step barrier.
 template <int H>
-__global__ __launch_bounds__(H) void lstm_seq_kernel(const float *__restrict__ gx, const float *__restrict__ whhT, int W,
-                                                     float *__restrict__ out) {
-    __shared__ float hs[2][H];
-    const int n = blockIdx.x, dir = blockIdx.y, j = threadIdx.x;
-    const float *g = gx + ((size_t)n * 2 + dir) * 4 * H * W;
-    const float *wt = whhT + (size_t)dir * H * 4 * H;
-    float *o = out + ((size_t)n * 2 * H + dir * H + j) * W;
-    float c = 0.f;
-    hs[0][j] = 0.f;
-    __syncthreads();
-    int cur = 0;
-    for (int s = 0; s < W; ++s) {
-        const int t = dir ? W - 1 - s : s;
-        float ai = g[(size_t)(0 * H + j) * W + t], af = g[(size_t)(1 * H + j) * W + t], ag = g[(size_t)(2 * H + j) * W + t],
-              ao = g[(size_t)(3 * H + j) * W + t];
-#pragma unroll 4
-        for (int k = 0; k < H; ++k) {
-            const float hk = hs[cur][k];
-            const float *r = wt + (size_t)k * 4 * H + j;
-            ai = fmaf(r[0], hk, ai); af = fmaf(r[H], hk, af); ag = fmaf(r[2 * H], hk, ag); ao = fmaf(r[3 * H], hk, ao);
-        }
-        c = sigmoid_f(af) * c + sigmoid_f(ai) * tanhf(ag);
-        const float h = sigmoid_f(ao) * tanhf(c);
-        o[t] = h;
-        hs[cur ^ 1][j] = h;
+__global__ __launch_bounds__(256) void lstm_step_kernel(const float *__restrict__ gx, const float *__restrict__ whh,
+                                                        const float *__restrict__ hprev, float *__restrict__ hnext,
+                                                        float *__restrict__ cst, float *__restrict__ out, int N, int W, int step) {
+    constexpr int RB = 4, NT = 32, KS = H / 16;
+    __shared__ float hs[NT][H + 4];
+    __shared__ float sums[4 * RB][NT + 1];
+    const int tid = threadIdx.x, dir = blockIdx.y, j0 = blockIdx.x * RB;
+    const int row = tid >> 4, ks = tid & 15;                 // row = gate * RB + unit, this thread's k slice
+    const int gate = row / RB, unit = row % RB;
+    const int t = dir ? W - 1 - step : step;
+    float w[KS];
+    const float *wr = whh + ((size_t)dir * 4 * H + gate * H + j0 + unit) * H + ks * KS;
+#pragma unroll
+    for (int k = 0; k < KS; ++k) w[k] = wr[k];
+    const float *hp = hprev + (size_t)dir * N * H;
+    for (int n0 = 0; n0 < N; n0 += NT) {
+        const int nn = min(NT, N - n0);
         __syncthreads();
-        cur ^= 1;
+        for (int i = tid; i < nn * H; i += 256) hs[i / H][i % H] = hp[(size_t)n0 * H + i];
+        __syncthreads();
+        for (int n = 0; n < nn; ++n) {
+            float a = 0.f;
+#pragma unroll
+            for (int k = 0; k < KS; ++k) a = fmaf(w[k], hs[n][ks * KS + k], a);
+            a += __shfl_xor(a, 1); a += __shfl_xor(a, 2); a += __shfl_xor(a, 4); a += __shfl_xor(a, 8);
+            if (ks == 0) sums[row][n] = a;
+        }
+        __syncthreads();
+        if (tid < RB * nn) {
+            const int u = tid % RB, n = n0 + tid / RB, j = j0 + u, nl = tid / RB;
+            const float *g = gx + (((size_t)n * 2 + dir) * 4 * H) * W + t;
+            const float ai = g[(size_t)(0 * H + j) * W] + sums[0 * RB + u][nl], af = g[(size_t)(1 * H + j) * W] + sums[1 * RB + u][nl],
+                        ag = g[(size_t)(2 * H + j) * W] + sums[2 * RB + u][nl], ao = g[(size_t)(3 * H + j) * W] + sums[3 * RB + u][nl];
+            const size_t si = ((size_t)dir * N + n) * H + j;
+            const float c = sigmoid_f(af) * cst[si] + sigmoid_f(ai) * tanhf(ag);
+            const float h = sigmoid_f(ao) * tanhf(c);
+            cst[si] = c;
+            hnext[si] = h;
+            out[((size_t)n * 2 * H + dir * H + j) * W + t] = h;
+        }
     }
 }
 
-int launch_lstm_seq(const float *gx, const float *whhT, int N, int H, int W, float *out, hipStream_t st) {
-    if (H == 192) hipLaunchKernelGGL(lstm_seq_kernel<192>, dim3(N, 2), dim3(192), 0, st, gx, whhT, W, out);
-    else if (H == 384) hipLaunchKernelGGL(lstm_seq_kernel<384>, dim3(N, 2), dim3(384), 0, st, gx, whhT, W, out);
-    else return set_error(MI_EINVAL, "lstm: hidden size %d not instantiated", H);
+// state: 3 buffers of 2 x N x H floats (h ping, h pong, c), zeroed here
+int launch_lstm_seq(const float *gx, const float *whh, int N, int H, int W, float *out, float *state, hipStream_t st) {
+    MI_REQUIRE(H == 192 || H == 384, "lstm: hidden size %d not instantiated", H);
+    const size_t sz = (size_t)2 * N * H;
+    MI_HIP(hipMemsetAsync(state, 0, 3 * sz * sizeof(float), st));
+    float *h0 = state, *h1 = state + sz, *c = state + 2 * sz;
+    const dim3 grid(H / 4, 2);
+    for (int s = 0; s < W; ++s) {
+        if (H == 192) hipLaunchKernelGGL(lstm_step_kernel<192>, grid, dim3(256), 0, st, gx, whh, h0, h1, c, out, N, W, s);
+        else hipLaunchKernelGGL(lstm_step_kernel<384>, grid, dim3(256), 0, st, gx, whh, h0, h1, c, out, N, W, s);
+        std::swap(h0, h1);
+    }
     MI_CHECK_LAUNCH();
     return MI_OK;
 }
@@ -150,12 +176,15 @@ int launch_lstm_seq(const float *gx, const float *whhT, int N, int H, int W, flo
 // ---- LocalState attention (demucs/demucs.py:182-216) ------------------------------------------------------------------
 // qkc (B, 3C + 16, T): rows [0, C) queries, [C, 2C) keys, [2C, 3C) content, [3C, 3C + 16) decay logits (heads x 4).
 // For query s of head h:  score(t) = k_t . q_s / sqrt(dh) - |t - s| * slope_s,  slope_s = sum_f (f + 1) * (sigmoid(d_f) / 2) / 2,
-// score(s) = -100, softmax over t, out[c][s] = sum_t w_t content[c][t].  One thread per query, keys staged in LDS.
+// score(s) = -100, softmax over t, out[c][s] = sum_t w_t content[c][t].
+// Workgroup = 8 queries x 8 key lanes: lane kl of a query takes keys kl, kl + 8, ... of every 64-key LDS tile with its own
+// online-softmax state; the 8 states of a query are merged with lane shuffles at the end (flash-decoding style split).
 template <int DH>
 __global__ __launch_bounds__(64) void local_attn_kernel(const float *__restrict__ qkc, int C, int T, float *__restrict__ out) {
-    constexpr int KT = 32;
+    constexpr int KT = 64;
     __shared__ float ks[KT][DH + 1], cs[KT][DH + 1];
-    const int b = blockIdx.z, h = blockIdx.y, s = blockIdx.x * 64 + threadIdx.x;
+    const int b = blockIdx.z, h = blockIdx.y, ql = threadIdx.x >> 3, kl = threadIdx.x & 7;
+    const int s = blockIdx.x * 8 + ql;
     const int rows = 3 * C + 16;
     const float *base = qkc + (size_t)b * rows * T;
     const bool ok = s < T;
@@ -177,9 +206,10 @@ __global__ __launch_bounds__(64) void local_attn_kernel(const float *__restrict_
             cs[tt][d] = t < T ? base[(size_t)(2 * C + h * DH + d) * T + t] : 0.f;
         }
         __syncthreads();
-        const int nt = min(KT, T - t0);
-        for (int tt = 0; tt < nt; ++tt) {
+#pragma unroll 2
+        for (int tt = kl; tt < KT; tt += 8) {
             const int t = t0 + tt;
+            if (t >= T) break;
             float sc = 0.f;
 #pragma unroll
             for (int d = 0; d < DH; ++d) sc = fmaf(ks[tt][d], q[d], sc);
@@ -198,7 +228,18 @@ __global__ __launch_bounds__(64) void local_attn_kernel(const float *__restrict_
             for (int d = 0; d < DH; ++d) acc[d] = fmaf(p, cs[tt][d], acc[d]);
         }
     }
-    if (ok) {
+    // merge the 8 key-lane states of the query (lanes kl = 0..7 are adjacent)
+#pragma unroll
+    for (int off = 1; off < 8; off <<= 1) {
+        const float mo = __shfl_xor(m, off), lo = __shfl_xor(l, off);
+        const float mn = fmaxf(m, mo);
+        const float a = mn == -INFINITY ? 0.f : expf(m - mn), bb = mn == -INFINITY ? 0.f : expf(mo - mn);
+        l = l * a + lo * bb;
+#pragma unroll
+        for (int d = 0; d < DH; ++d) acc[d] = acc[d] * a + __shfl_xor(acc[d], off) * bb;
+        m = mn;
+    }
+    if (ok && kl == 0) {
         const float inv = 1.0f / l;
 #pragma unroll
         for (int d = 0; d < DH; ++d) out[((size_t)b * C + h * DH + d) * T + s] = acc[d] * inv;
@@ -206,7 +247,7 @@ __global__ __launch_bounds__(64) void local_attn_kernel(const float *__restrict_
 }
 
 int launch_local_attn(const float *qkc, int B, int C, int T, float *out, hipStream_t st) {
-    const dim3 grid(ceil_div(T, 64), 4, B);
+    const dim3 grid(ceil_div(T, 8), 4, B);
     if (C == 192) hipLaunchKernelGGL(local_attn_kernel<48>, grid, dim3(64), 0, st, qkc, C, T, out);
     else if (C == 384) hipLaunchKernelGGL(local_attn_kernel<96>, grid, dim3(64), 0, st, qkc, C, T, out);
     else return set_error(MI_EINVAL, "local_attn: %d channels not instantiated", C);

@@ -11,7 +11,7 @@ namespace mi {
 
 struct HDeepLayerW {            // one DConv layer with BLSTM + LocalState (encoder layers 4, 5; demucs/demucs.py:133-149)
     PackedConv conv3, ih[2], lin, qkc, proj, conv1;
-    float *whhT[2] = {};        // per LSTM layer: [2 dirs][H][4H] = W_hh^T
+    float *whhT[2] = {};        // per LSTM layer: [2 dirs][4H][H] = W_hh (rows contiguous)
     float *g1w = nullptr, *g1b = nullptr, *g2w = nullptr, *g2b = nullptr, *ls = nullptr;
 };
 struct HEncW {
@@ -43,7 +43,7 @@ struct HModel : Model {
     float *x_a = nullptr, *x_b = nullptr, *x_h = nullptr, *x_ta = nullptr, *x_tb = nullptr, *x_th = nullptr;
     float *x_zA = nullptr, *x_zB = nullptr, *x_a4 = nullptr, *x_b4 = nullptr, *x_pre = nullptr;
     float *x_dh = nullptr, *x_dy1 = nullptr, *x_dy2 = nullptr, *x_dy3 = nullptr, *x_xf = nullptr, *x_gx = nullptr, *x_o0 = nullptr,
-          *x_o1 = nullptr, *x_xl = nullptr, *x_qkc = nullptr, *x_att = nullptr;
+          *x_o1 = nullptr, *x_xl = nullptr, *x_qkc = nullptr, *x_att = nullptr, *x_lstm = nullptr;
     float *x_dec[6] = {}, *x_tdec[5] = {}, *x_yt = nullptr, *x_fr = nullptr;
     double *x_stats = nullptr, *x_stats_t = nullptr;
     float2 *x_st1 = nullptr, *x_st2 = nullptr, *x_st1t = nullptr, *x_st2t = nullptr, *x_nf = nullptr, *x_df = nullptr, *x_nt = nullptr,

@@ -59,7 +59,7 @@ int HModel::load_deep(const WeightTable &wt, const std::string &prefix, int C, H
             memcpy(&wih[(size_t)dir * 4 * H * Kin], a, sizeof(float) * 4 * H * Kin);
             for (int r = 0; r < 4 * H; ++r) {
                 bih[dir * 4 * H + r] = b1[r] + b2[r];
-                for (int k = 0; k < H; ++k) whh[((size_t)dir * H + k) * 4 * H + r] = hh[(size_t)r * H + k];
+                for (int k = 0; k < H; ++k) whh[((size_t)dir * 4 * H + r) * H + k] = hh[(size_t)r * H + k];
             }
         }
         MI_TRY(pack_conv(wih.data(), bih.data(), 8 * H, Kin, false, &l->ih[layer]));
@@ -208,6 +208,7 @@ int HModel::hinit(const mi_config &c, const mi_tensor_desc *weights, size_t n) {
     MI_TRY(A(&x_dh, 384 * T)); MI_TRY(A(&x_dy1, 384 * T)); MI_TRY(A(&x_dy2, 384 * T)); MI_TRY(A(&x_dy3, 384 * T));
     MI_TRY(A(&x_xf, 384 * fw)); MI_TRY(A(&x_gx, 3072 * fw)); MI_TRY(A(&x_o0, 768 * fw)); MI_TRY(A(&x_o1, 768 * fw)); MI_TRY(A(&x_xl, 384 * fw));
     MI_TRY(A(&x_qkc, (3 * 384 + 16) * T)); MI_TRY(A(&x_att, 384 * T));
+    MI_TRY(A(&x_lstm, 6 * 384 * (fw / 200 + 2)));          // LSTM state: h ping / pong and c for every (direction, sequence)
     MI_TRY(A(&x_dec[0], 768 * T)); MI_TRY(A(&x_dec[1], 384 * 8 * T)); MI_TRY(A(&x_dec[2], 192 * 32 * T)); MI_TRY(A(&x_dec[3], 96 * 128 * T));
     MI_TRY(A(&x_dec[4], 48 * 512 * T)); MI_TRY(A(&x_dec[5], (size_t)4 * S * 2048 * T));
     MI_TRY(A(&x_tdec[0], (size_t)384 * lp[4])); MI_TRY(A(&x_tdec[1], (size_t)192 * lp[3])); MI_TRY(A(&x_tdec[2], (size_t)96 * lp[2]));
@@ -312,7 +313,7 @@ int HModel::run_deep(HGeo &g, HEncW &e, int C, int Tn, int B, float *x, float *t
             mi_conv_desc gi = base_desc(l.ih[layer], k, layer ? x_o0 : xin, (int64_t)Kin * W, gs);
             gi.plain = 1; gi.epi = MI_EPI_LINEAR; gi.y = x_gx; gi.y_bstride = (int64_t)8 * H * W; gi.y_cstride = W;
             MI_TRY(conv(gi, st));
-            MI_TRY(launch_lstm_seq(x_gx, l.whhT[layer], N, H, W, layer ? x_o1 : x_o0, st));
+            MI_TRY(launch_lstm_seq(x_gx, l.whhT[layer], N, H, W, layer ? x_o1 : x_o0, x_lstm, st));
         }
         MI_TRY(ktab(g, Gather{2 * H, 1, 1, 1, 1, 0, 0, (int64_t)W, W}, l.lin.Kpad, &k));
         mi_conv_desc li = base_desc(l.lin, k, x_o1, (int64_t)2 * H * W, gs);
