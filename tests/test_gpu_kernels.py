@@ -264,6 +264,26 @@ def test_dconv_layer_three_passes(lib, freq, x6):
     assert maxerr(out, want) < chained_tol(3e-5)
 
 
+def test_gelu_erf_form_accuracy(lib):
+    """`gelu_exact` (csrc/common.h) through mi_gn_gelu with identity statistics, on a dense grid and on tiny arguments,
+    against the float64 erf form of F.gelu (reference: nn.GELU default in demucs/demucs.py:116 and transformer.py:339).
+    Bar: 1.5e-7 |x| + 1e-9 -- tighter than float32 F.gelu on the host reaches."""
+    n = 1 << 20
+    x = torch.cat([torch.linspace(-9, 9, n - 4096, dtype=torch.float64), torch.logspace(-8, 0, 2048, dtype=torch.float64),
+                   -torch.logspace(-8, 0, 2048, dtype=torch.float64)]).float()
+    xd = x.clone().cuda().view(1, 1, 1, n)
+    st = torch.tensor([[0.0, 1.0]], device="cuda")
+    one, zero = torch.ones(1, device="cuda"), torch.zeros(1, device="cuda")
+    _lib.check(lib.mi_gn_gelu(xd.data_ptr(), 1, 1, 1, 1, n, 0, st.data_ptr(), one.data_ptr(), zero.data_ptr(), stream()), "mi_gn_gelu")
+    torch.cuda.synchronize()
+    x64 = x.double()
+    want = 0.5 * x64 * (1 + torch.erf(x64 * math.sqrt(0.5)))
+    err = (xd.view(-1).cpu().double() - want).abs()
+    rel = (err / (1.5e-7 * x64.abs() + 1e-9)).max().item()
+    print(f"gelu: max abs err {err.max():.2e}, worst err / (1.5e-7 |x| + 1e-9) = {rel:.2f}")
+    assert rel <= 1.0
+
+
 @pytest.mark.parametrize("dtype", [0, 1, 2], ids=["f32", "bf16", "f16"])
 def test_attention_matches_softmax(lib, dtype):
     """softmax(QK^T/8)V per head on channel-first q/k/v, ragged Tq (not a multiple of 128), cross
