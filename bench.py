@@ -261,11 +261,12 @@ def main():
                 m2.release()
             del mix3
             # BASELINE configs[4], second model: the hdemucs_mmi architecture (Hybrid Demucs v3: BLSTM + LocalState, 44 s
-            # segments as remote/hdemucs_mmi.yaml sets) in the fp16 mode on a 3-minute track, one chunk per forward
+            # segments as remote/hdemucs_mmi.yaml sets) in the fp16 mode on a 3-minute track: the five full chunks in one batched
+            # forward, the 15 s tail chunk in a second one
             from demucs_amd.hdemucs import HDemucs
             from demucs_amd.hdemucs_weights import HDemucsConfig, synthetic_hdemucs_state_dict
             hcfg = HDemucsConfig()
-            hm = HDemucs(hcfg.sources, max_batch=1, compute_dtype="f16")
+            hm = HDemucs(hcfg.sources, max_batch=5, compute_dtype="f16")
             hm.load_state_dict(synthetic_hdemucs_state_dict(hcfg, 0))
             hm.to(dev).eval()
             hbag = P.BagOfModels([hm], segment=44)
@@ -279,7 +280,8 @@ def main():
             assert o.shape == (1, 4, 2, TRACK_SECONDS * SR) and bool(torch.isfinite(o[0, :, 0, ::997]).all())
             result["modes"]["hdemucs_mmi fp16"] = {"dtype": "f16", "sources": 4, "value": round(TRACK_SECONDS / dt_s, 2), "unit": "audio-sec/wall-sec",
                                                    "ms_per_step": round(dt_s * 1e3, 2), "steps": 1,
-                                                   "note": "6 chunks of up to 44 s (overlap 0.25), each one forward at its own length"}
+                                                   "device_bytes": hm.device_bytes(),
+                                                   "note": "6 chunks (overlap 0.25): five of 44 s in one batched forward, the 15 s tail in another"}
             del o, hmix
             hm.release()
         if world == 1 and not args.no_cpu_baseline:

@@ -285,7 +285,7 @@ def _segment_plan(model, length: int, overlap: float, segment):
 
 def _apply_split(model, mix, common, callback, callback_arg) -> torch.Tensor:
     """apply.py:257-301."""
-    if isinstance(model, HTDemucs) and common["device"].type == "cuda":
+    if isinstance(model, (HTDemucs, HDemucs)) and common["device"].type == "cuda":
         return _apply_split_device(model, mix, common, callback, callback_arg)
     kw = dict(common, split=False)
     device, pool = common["device"], common["pool"]
@@ -432,6 +432,49 @@ def device_split_accumulate(model: HTDemucs, base: torch.Tensor, chunk_offset: i
                                              span_hi, weight.data_ptr(), weight.numel(), stream()), "mi_ola_accumulate")
 
 
+def ragged_split_accumulate(model: HDemucs, base: torch.Tensor, chunk_offset: int, length: int, offsets: Sequence[int],
+                            segment_length: int, weight: torch.Tensor, acc: torch.Tensor,
+                            on_start: Optional[Callable[[int], None]] = None,
+                            on_end: Optional[Callable[[int], None]] = None) -> None:
+    """`device_split_accumulate` for a model WITHOUT `valid_length` (HDemucs): the leaf forwards every chunk at its own
+    length, unpadded (apply.py:309-310), so consecutive chunks of equal length -- all but the last of a track -- share one
+    gather, one batched forward of up to `model.max_batch` chunks and one overlap-add; the shorter tail chunk gets its
+    own.  Events fire in the reference's order (start, end, start, end ...), as in `device_split_accumulate`."""
+    lib = _lib.load()
+    dev = base.device
+    channels, total = base.shape
+    rows = acc.shape[0]
+    stream = lambda: C.c_void_p(_lib.current_stream_ptr())          # noqa: E731
+    lens = [min(length - o, segment_length) for o in offsets]
+    if weight.numel() < max(lens):
+        raise ValueError(f"the weight ramp ({weight.numel()}) is shorter than a chunk ({max(lens)})")
+    with torch.cuda.device(dev):
+        i = 0
+        while i < len(offsets):
+            n, j = lens[i], i + 1
+            while j < len(offsets) and j - i < model.max_batch and lens[j] == n:
+                j += 1
+            offs, nb = list(offsets[i:j]), j - i
+            i = j
+            seg = torch.empty(nb, channels, n, device=dev, dtype=torch.float32)
+            t_starts = _i64([chunk_offset + o for o in offs], dev)
+            _lib.check(lib.mi_segments_gather(base.data_ptr(), total, channels, t_starts.data_ptr(), nb, n, seg.data_ptr(),
+                                              seg.numel(), stream()), "mi_segments_gather")
+            if on_start is not None:
+                on_start(offs[0])
+            out = model(seg)
+            for k, o in enumerate(offs):
+                if k and on_start is not None:
+                    on_start(o)
+                if on_end is not None:
+                    on_end(o)
+            t_offs, t_lens, t_trims = _i64(offs, dev), _i32([n] * nb, dev), _i32([0] * nb, dev)
+            _lib.check(lib.mi_ola_accumulate(acc.data_ptr(), acc.shape[1], rows, out.data_ptr(), n, out.numel(),
+                                             t_offs.data_ptr(), t_lens.data_ptr(), t_trims.data_ptr(), nb, offs[0],
+                                             min(acc.shape[1], offs[-1] + n), weight.data_ptr(), weight.numel(), stream()),
+                       "mi_ola_accumulate")
+
+
 def device_split_finish(acc: torch.Tensor, acc_origin: int, length: int, offsets: Sequence[int], segment_length: int,
                         weight: torch.Tensor) -> None:
     """`out /= sum_weight` on the device, sum_weight rebuilt from ALL segment offsets of the chunk."""
@@ -445,12 +488,13 @@ def device_split_finish(acc: torch.Tensor, acc_origin: int, length: int, offsets
                                      C.c_void_p(_lib.current_stream_ptr())), "mi_ola_finish")
 
 
-def _apply_split_device(model: HTDemucs, mix, common, callback, callback_arg) -> torch.Tensor:
+def _apply_split_device(model, mix, common, callback, callback_arg) -> torch.Tensor:
     device, lock = common["device"], common["lock"]
     chunk = tensor_chunk(mix)
     batch, channels, length = chunk.shape
     seg, segment_length, stride, offsets = _segment_plan(model, length, common["overlap"], common["segment"])
-    valid_length = _leaf_valid_length(model, segment_length, common["segment"])
+    ragged = isinstance(model, HDemucs)
+    valid_length = None if ragged else _leaf_valid_length(model, segment_length, common["segment"])
     weight = _transition_weight(segment_length, common["transition_power"], device).to(torch.float32).contiguous()
     S = len(model.sources)
     on_device = mix.device == device
@@ -479,8 +523,12 @@ def _apply_split_device(model: HTDemucs, mix, common, callback, callback_arg) ->
         first = b == 0
         base = chunk.tensor[b].to(device=device, dtype=torch.float32).contiguous()       # whole track resident in HBM
         acc = out[b].view(S * channels, length) if on_device else torch.zeros(S * channels, length, device=device, dtype=torch.float32)
-        device_split_accumulate(model, base, chunk.offset, length, offsets, segment_length, valid_length, weight, acc, 0,
-                                on_start if first else None, on_end if first else None, draw_rng=first)
+        if ragged:
+            ragged_split_accumulate(model, base, chunk.offset, length, offsets, segment_length, weight, acc,
+                                    on_start if first else None, on_end if first else None)
+        else:
+            device_split_accumulate(model, base, chunk.offset, length, offsets, segment_length, valid_length, weight, acc, 0,
+                                    on_start if first else None, on_end if first else None, draw_rng=first)
         device_split_finish(acc, 0, length, offsets, segment_length, weight)
         if not on_device:
             out[b] = acc.view(S, channels, length).to(mix.device)

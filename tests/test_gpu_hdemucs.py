@@ -86,11 +86,13 @@ def test_full_resolution_vs_float64_oracle_and_batching():
     assert torch.equal(single[0], out[1])
 
 
-def test_apply_model_matches_reference(golden):
-    """`apply_model` around the engine with a segment override: chunks of 176 400 samples and a last one of 52 933, each
-    forwarded at its own length (the reference's HDemucs has no valid_length); host mix in, result on the host."""
+@pytest.mark.parametrize("max_batch", [1, 2])
+def test_apply_model_matches_reference(golden, max_batch):
+    """`apply_model` around the engine with a segment override: three chunks of 176 400 samples and a last one of 52 933,
+    each forwarded at its own length (the reference's HDemucs has no valid_length) -- equal-length chunks batched up to
+    `max_batch` per forward, same events in the same order; host mix in, result on the host."""
     g = golden("happly_10s_seg4")
-    m = engine(int(g.meta("wseed")))
+    m = engine(int(g.meta("wseed")), max_batch=max_batch)
     kw = {k[len("meta/kw_"):]: g.z[k].item() for k in g.z.files if k.startswith("meta/kw_")}
     mix = torch.from_numpy(synth_mix(23, 449833, "tones"))[None]
     events = []
