@@ -105,56 +105,92 @@ int launch_restitch_frames(const float *fr, int B, int C, int T, int F, int W, i
 }
 
 // ---- LSTM recurrence (nn.LSTM semantics, zero initial state, gate order i, f, g, o) ------------------------------------
-// gx (N, 2 dirs, 4H, W): W_ih x_t + b_ih + b_hh for every step (a GEMM done before); whh (2 dirs, 4H, H) = W_hh;
-// out (N, 2H, W): forward hidden states in channels [0, H), backward ones in [H, 2H).
+// gx (N, 2 dirs, 4H, W): W_ih x_t + b_ih + b_hh for every step (a GEMM done before); out (N, 2H, W): forward hidden states
+// in channels [0, H), backward ones in [H, 2H).
 // ONE LAUNCH PER TIME STEP: the recurrent matrix (2.4 MB per direction at H = 384) cannot stream through one CU per step
-// (a persistent workgroup per sequence ran at 36 us per step), so every step spreads it over (H / 4) x 2 workgroups: a
-// workgroup owns 4 hidden units (their 16 gate rows, held in registers: 24 / 12 weights per thread) of one direction for
-// ALL sequences, reads the previous hidden states (N x H, L2 resident) tile by tile into LDS, reduces the 16 k slices of
-// a row with lane shuffles and applies the gate non-linearities.  The hidden state ping-pongs between two global buffers;
-// the launch boundary is the step barrier.
+// (a persistent workgroup per sequence ran at 36 us per step), so every step spreads it over (H / 4) x 2 x ceil(N / 32)
+// workgroups: a workgroup owns 4 hidden units (their 16 gate rows) of one direction for a tile of 32 sequences and
+// computes the 16 x 32 block  W_hh[rows, :] . h_prev[:, tile]  on the matrix pipe -- v_mfma_f32_16x16x4_f32, exact
+// float32 products; each of the 4 waves takes a quarter of the k range (its weights stay in 12 / 24 registers, the
+// previous hidden states come from an LDS image of the tile) and the four partial blocks are summed by the gate threads.
+// whh is packed for that (pack_lstm_whh below): [dir][H / 4 unit blocks][wave][k step / 4][lane][4], the element of lane l
+// at k step i being W_hh[gate (l % 16) / 4, unit (l % 16) % 4][k = wave * H / 4 + 4 i + l / 16].
+// The hidden state ping-pongs between two global buffers; the launch boundary is the step barrier.
+typedef float v4f __attribute__((ext_vector_type(4)));
+
 template <int H>
 __global__ __launch_bounds__(256) void lstm_step_kernel(const float *__restrict__ gx, const float *__restrict__ whh,
                                                         const float *__restrict__ hprev, float *__restrict__ hnext,
                                                         float *__restrict__ cst, float *__restrict__ out, int N, int W, int step) {
-    constexpr int RB = 4, NT = 32, KS = H / 16;
+    constexpr int RB = 4, NT = 32, KW = H / 4, NK = KW / 4;
     __shared__ float hs[NT][H + 4];
-    __shared__ float sums[4 * RB][NT + 1];
-    const int tid = threadIdx.x, dir = blockIdx.y, j0 = blockIdx.x * RB;
-    const int row = tid >> 4, ks = tid & 15;                 // row = gate * RB + unit, this thread's k slice
-    const int gate = row / RB, unit = row % RB;
+    __shared__ float part[4][4 * RB][NT + 1];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, dir = blockIdx.y, jb = blockIdx.x, j0 = jb * RB;
     const int t = dir ? W - 1 - step : step;
-    float w[KS];
-    const float *wr = whh + ((size_t)dir * 4 * H + gate * H + j0 + unit) * H + ks * KS;
-#pragma unroll
-    for (int k = 0; k < KS; ++k) w[k] = wr[k];
-    const float *hp = hprev + (size_t)dir * N * H;
-    for (int n0 = 0; n0 < N; n0 += NT) {
-        const int nn = min(NT, N - n0);
-        __syncthreads();
-        for (int i = tid; i < nn * H; i += 256) hs[i / H][i % H] = hp[(size_t)n0 * H + i];
-        __syncthreads();
-        for (int n = 0; n < nn; ++n) {
-            float a = 0.f;
-#pragma unroll
-            for (int k = 0; k < KS; ++k) a = fmaf(w[k], hs[n][ks * KS + k], a);
-            a += __shfl_xor(a, 1); a += __shfl_xor(a, 2); a += __shfl_xor(a, 4); a += __shfl_xor(a, 8);
-            if (ks == 0) sums[row][n] = a;
-        }
-        __syncthreads();
-        if (tid < RB * nn) {
-            const int u = tid % RB, n = n0 + tid / RB, j = j0 + u, nl = tid / RB;
-            const float *g = gx + (((size_t)n * 2 + dir) * 4 * H) * W + t;
-            const float ai = g[(size_t)(0 * H + j) * W] + sums[0 * RB + u][nl], af = g[(size_t)(1 * H + j) * W] + sums[1 * RB + u][nl],
-                        ag = g[(size_t)(2 * H + j) * W] + sums[2 * RB + u][nl], ao = g[(size_t)(3 * H + j) * W] + sums[3 * RB + u][nl];
-            const size_t si = ((size_t)dir * N + n) * H + j;
-            const float c = sigmoid_f(af) * cst[si] + sigmoid_f(ai) * tanhf(ag);
-            const float h = sigmoid_f(ao) * tanhf(c);
-            cst[si] = c;
-            hnext[si] = h;
-            out[((size_t)n * 2 * H + dir * H + j) * W + t] = h;
-        }
+    const int n0 = blockIdx.z * NT, nn = min(NT, N - n0);
+    // the gate threads fetch their pre-activations and cell state first: the strided reads land while the products run
+    const bool gate_thread = tid < RB * nn;
+    const int gu = tid % RB, gnl = tid / RB, gn = n0 + gnl, gj = j0 + gu;
+    const size_t si = ((size_t)dir * N + gn) * H + gj;
+    float pi = 0.f, pf = 0.f, pg = 0.f, po = 0.f, pc = 0.f;
+    if (gate_thread) {
+        const float *g = gx + (((size_t)gn * 2 + dir) * 4 * H) * W + t;
+        pi = g[(size_t)(0 * H + gj) * W]; pf = g[(size_t)(1 * H + gj) * W];
+        pg = g[(size_t)(2 * H + gj) * W]; po = g[(size_t)(3 * H + gj) * W];
+        pc = cst[si];
     }
+    float a[NK];
+    const float4 *wp = (const float4 *)(whh + (((size_t)dir * (H / RB) + jb) * 4 + wave) * NK * 64) + lane;
+#pragma unroll
+    for (int q = 0; q < NK / 4; ++q) {
+        const float4 v = wp[q * 64];
+        a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
+    }
+    const float4 *hp4 = (const float4 *)(hprev + ((size_t)dir * N + n0) * H);
+    for (int i = tid; i < NT * (H / 4); i += 256) {          // rows beyond the tile's sequences read as zero
+        const int n = i / (H / 4);
+        *(float4 *)&hs[n][(i % (H / 4)) * 4] = n < nn ? hp4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    v4f c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+    const float *b0 = &hs[lane & 15][wave * KW + (lane >> 4)], *b1 = &hs[16 + (lane & 15)][wave * KW + (lane >> 4)];
+#pragma unroll
+    for (int i = 0; i < NK; ++i) {
+        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b0[4 * i], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b1[4 * i], c1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {                             // D[row 4 (lane / 16) + r][col lane % 16]
+        part[wave][4 * (lane >> 4) + r][lane & 15] = c0[r];
+        part[wave][4 * (lane >> 4) + r][16 + (lane & 15)] = c1[r];
+    }
+    __syncthreads();
+    if (gate_thread) {
+        float s4[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            s4[g] = (part[0][g * RB + gu][gnl] + part[1][g * RB + gu][gnl]) + (part[2][g * RB + gu][gnl] + part[3][g * RB + gu][gnl]);
+        const float ai = pi + s4[0], af = pf + s4[1], ag = pg + s4[2], ao = po + s4[3];
+        const float c = sigmoid_f(af) * pc + sigmoid_f(ai) * tanhf(ag);
+        const float h = sigmoid_f(ao) * tanhf(c);
+        cst[si] = c;
+        hnext[si] = h;
+        out[((size_t)gn * 2 * H + dir * H + gj) * W + t] = h;
+    }
+}
+
+// W_hh of both directions (2, 4H, H) -> the step kernel's operand order; `packed` holds 2 * 4H * H floats
+void pack_lstm_whh(const float *whh, int H, float *packed) {
+    const int KW = H / 4, NK = KW / 4;
+    for (int dir = 0; dir < 2; ++dir)
+        for (int jb = 0; jb < H / 4; ++jb)
+            for (int wave = 0; wave < 4; ++wave)
+                for (int i = 0; i < NK; ++i)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int r = lane & 15, row = (r / 4) * H + jb * 4 + r % 4, k = wave * KW + 4 * i + (lane >> 4);
+                        packed[((((size_t)dir * (H / 4) + jb) * 4 + wave) * NK + (i / 4) * 4) * 64 + lane * 4 + i % 4] =
+                            whh[((size_t)dir * 4 * H + row) * H + k];
+                    }
 }
 
 // state: 3 buffers of 2 x N x H floats (h ping, h pong, c), zeroed here
@@ -163,7 +199,7 @@ int launch_lstm_seq(const float *gx, const float *whh, int N, int H, int W, floa
     const size_t sz = (size_t)2 * N * H;
     MI_HIP(hipMemsetAsync(state, 0, 3 * sz * sizeof(float), st));
     float *h0 = state, *h1 = state + sz, *c = state + 2 * sz;
-    const dim3 grid(H / 4, 2);
+    const dim3 grid(H / 4, 2, ceil_div(N, 32));
     for (int s = 0; s < W; ++s) {
         if (H == 192) hipLaunchKernelGGL(lstm_step_kernel<192>, grid, dim3(256), 0, st, gx, whh, h0, h1, c, out, N, W, s);
         else hipLaunchKernelGGL(lstm_step_kernel<384>, grid, dim3(256), 0, st, gx, whh, h0, h1, c, out, N, W, s);

@@ -11,7 +11,7 @@ namespace mi {
 
 struct HDeepLayerW {            // one DConv layer with BLSTM + LocalState (encoder layers 4, 5; demucs/demucs.py:133-149)
     PackedConv conv3, ih[2], lin, qkc, proj, conv1;
-    float *whhT[2] = {};        // per LSTM layer: [2 dirs][4H][H] = W_hh (rows contiguous)
+    float *whhT[2] = {};        // per LSTM layer: W_hh of both directions in the step kernel's operand order (pack_lstm_whh)
     float *g1w = nullptr, *g1b = nullptr, *g2w = nullptr, *g2b = nullptr, *ls = nullptr;
 };
 struct HEncW {

@@ -63,7 +63,9 @@ int HModel::load_deep(const WeightTable &wt, const std::string &prefix, int C, H
             }
         }
         MI_TRY(pack_conv(wih.data(), bih.data(), 8 * H, Kin, false, &l->ih[layer]));
-        MI_TRY(upload(whh, &l->whhT[layer]));
+        std::vector<float> packed(whh.size());
+        pack_lstm_whh(whh.data(), H, packed.data());
+        MI_TRY(upload(packed, &l->whhT[layer]));
     }
     MI_TRY(wt.get(p + ".3.linear.weight", (int64_t)H * 2 * H, &w)); MI_TRY(wt.get(p + ".3.linear.bias", H, &b));
     MI_TRY(pack_conv(w, b, H, 2 * H, false, &l->lin));

@@ -86,7 +86,8 @@ int launch_gn_apply(const float *x, int B, int Cin, int G, int in_pitch, int off
                     int out_pitch, hipStream_t st, int chan_div = 1);
 int launch_unfold_frames(const float *x, int B, int C, int T, int F, int W, int S, float *fr, hipStream_t st);
 int launch_restitch_frames(const float *fr, int B, int C, int T, int F, int W, int S, const float *skip, float *y, hipStream_t st);
-int launch_lstm_seq(const float *gx, const float *whh, int N, int H, int W, float *out, float *state /* 6 N H floats */, hipStream_t st);
+void pack_lstm_whh(const float *whh /* (2, 4H, H) */, int H, float *packed);     // host side: the step kernel's operand order
+int launch_lstm_seq(const float *gx, const float *whh /* packed */, int N, int H, int W, float *out, float *state /* 6 N H floats */, hipStream_t st);
 int launch_local_attn(const float *qkc, int B, int C, int T, float *out, hipStream_t st);
 
 // attention.hip
