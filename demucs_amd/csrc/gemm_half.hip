@@ -89,13 +89,15 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_half_kernel(const mi_conv_de
 
     // ---- A loader: the K step's image is 4 runs of BM 16-byte words ----------------------------------
     constexpr int A_W = 4 * BM, A_FULL = A_W / 256, A_REM = A_W % 256, A_SLOTS = A_FULL + (A_REM ? 1 : 0);
-    static_assert(A_SLOTS <= 2, "A tile fits two 16-byte words per thread");
-    const bool a_on0 = tid < A_W, a_on1 = tid + 256 < A_W;
-    const int ai0 = a_on0 ? tid : 0, ai1 = a_on1 ? tid + 256 : 0;
-    const int ao0 = ai0 / BM, am0 = ai0 % BM, ao1 = ai1 / BM, am1 = ai1 % BM;
+    static_assert(A_SLOTS <= 4, "A tile fits four 16-byte words per thread");
+    const bool a_on0 = tid < A_W, a_on1 = tid + 256 < A_W, a_on2 = tid + 512 < A_W, a_on3 = tid + 768 < A_W;
+    const int ai0 = a_on0 ? tid : 0, ai1 = a_on1 ? tid + 256 : 0, ai2 = a_on2 ? tid + 512 : 0, ai3 = a_on3 ? tid + 768 : 0;
+    const int ao0 = ai0 / BM, am0 = ai0 % BM, ao1 = ai1 / BM, am1 = ai1 % BM, ao2 = ai2 / BM, am2 = ai2 % BM, ao3 = ai3 / BM, am3 = ai3 % BM;
     const uint4 *wh = reinterpret_cast<const uint4 *>(d.wh);
     const uint4 *ap0 = wh + (size_t)ao0 * d.Mpad + m0 + am0;
     const uint4 *ap1 = wh + (size_t)ao1 * d.Mpad + m0 + am1;
+    const uint4 *ap2 = wh + (size_t)ao2 * d.Mpad + m0 + am2;
+    const uint4 *ap3 = wh + (size_t)ao3 * d.Mpad + m0 + am3;
     const size_t a_step = (size_t)4 * d.Mpad;
 
     // ---- B loader: thread = (column bn, k half bh): k = 16 bh .. 16 bh + 15 of the K step ---------------
@@ -107,7 +109,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_half_kernel(const mi_conv_de
 
     // TWO register sets: the loads of K steps k+1 and k+2 are both in flight under the MFMAs of step k (the main loop is
     // latency bound otherwise: one 24 KiB tile per workgroup in flight keeps the L2 at ~10 TB/s and the matrix pipe at 11 %)
-    uint4 areg0 = make_uint4(0, 0, 0, 0), areg1 = areg0;      // weights (L2 resident) and gathered activations: one step ahead
+    uint4 areg0 = make_uint4(0, 0, 0, 0), areg1 = areg0, areg2 = areg0, areg3 = areg0;      // weights (L2 resident) and gathered activations: one step ahead
     float breg[1][16];
     // PLAIN (1x1 / linear, channel stride P, P % 4 == 0): thread = (column quad q, pair group pg) loads rows 2 pg, 2 pg + 1,
     // 16 + 2 pg, 17 + 2 pg of the K step as float4 along n (4 VMEM instructions instead of 16 dword loads), packs the two
@@ -145,6 +147,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_half_kernel(const mi_conv_de
     do {                                                                                              \
         if (A_SLOTS >= 1) areg0 = ap0[(size_t)(kt) * a_step];                                            \
         if (A_SLOTS >= 2) areg1 = ap1[(size_t)(kt) * a_step];                                            \
+        if (A_SLOTS >= 3) areg2 = ap2[(size_t)(kt) * a_step];                                            \
+        if (A_SLOTS >= 4) areg3 = ap3[(size_t)(kt) * a_step];                                            \
     } while (0)
 
 #define MI_STORE_TILE(buf, S)                                                                         \
@@ -163,6 +167,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_half_kernel(const mi_conv_de
         }                                                                                             \
         if (A_SLOTS >= 1 && a_on0) As[buf][ao0][am0] = areg0;                                         \
         if (A_SLOTS >= 2 && a_on1) As[buf][ao1][am1] = areg1;                                         \
+        if (A_SLOTS >= 3 && a_on2) As[buf][ao2][am2] = areg2;                                         \
+        if (A_SLOTS >= 4 && a_on3) As[buf][ao3][am3] = areg3;                                         \
     } while (0)
 
     f32x16 acc[TM][TN];
@@ -240,6 +246,11 @@ static int launch_cfg_half(const mi_conv_desc &d, hipStream_t st) {
 
 template <int HT, int EPI, int LFLAGS, bool PLAIN>
 static int launch_tile_half(const mi_conv_desc &d, int tile, hipStream_t st) {
+    if constexpr (PLAIN && EPI == MI_EPI_LINEAR) {
+        // 256 x 128 for the transformer's linear layers: the 128 x 128 tile is bound by cache bandwidth (43 FLOP per byte of
+        // float32 activations + 16-bit weights); twice the rows per activation tile brings that to 64
+        if (tile == 256) return launch_cfg_half<HT, 2, 2, 4, 2, EPI, LFLAGS, PLAIN>(d, st);
+    }
     switch (tile) {
         case 128: return launch_cfg_half<HT, 2, 2, 2, 2, EPI, LFLAGS, PLAIN>(d, st);
         case 96: return launch_cfg_half<HT, 1, 4, 3, 1, EPI, LFLAGS, PLAIN>(d, st);
@@ -283,6 +294,8 @@ int launch_conv_half(const mi_conv_desc &d, int tile, bool plain, hipStream_t st
     MI_REQUIRE(d.wh && ((uintptr_t)d.wh & 15) == 0, "conv half: weight image missing or misaligned");
     MI_REQUIRE(plain || d.ktab_len >= (d.Kpad + HK - 1) / HK * HK, "conv half: gather table has %d entries, the K step of %d needs %d",
                d.ktab_len, HK, (d.Kpad + HK - 1) / HK * HK);
+    static const bool wide = [] { const char *e = getenv("MI_HALF_TILE256"); return !e || atoi(e) != 0; }();
+    if (wide && plain && tile == 128 && d.epi == MI_EPI_LINEAR && d.Mpad % 256 == 0) tile = 256;
     if (d.half == MI_DTYPE_BF16) return launch_conv_half_t<MI_DTYPE_BF16>(d, tile, plain, st);
     if (d.half == MI_DTYPE_F16) return launch_conv_half_t<MI_DTYPE_F16>(d, tile, plain, st);
     return set_error(MI_EINVAL, "conv half: operand type %d", d.half);
