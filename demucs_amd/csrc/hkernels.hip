@@ -1,6 +1,7 @@
 // Kernels of the Hybrid Demucs v3 (`hdemucs_mmi`) path that the htdemucs engine has no counterpart for
 // (reference: demucs/hdemucs.py:92-157,304-335 GroupNorm(4) inside the layers; demucs/demucs.py:20-67 BLSTM with
-// overlapping 200-step chunks; demucs/demucs.py:182-216 LocalState attention).  All float32.
+// overlapping 200-step chunks; demucs/demucs.py:182-216 LocalState attention).  All float32 (matrix-pipe products are the exact
+// float32 MFMA forms).
 #include "common.h"
 #include "kernels.h"
 
@@ -117,6 +118,7 @@ int launch_restitch_frames(const float *fr, int B, int C, int T, int F, int W, i
 // at k step i being W_hh[gate (l % 16) / 4, unit (l % 16) % 4][k = wave * H / 4 + 4 i + l / 16].
 // The hidden state ping-pongs between two global buffers; the launch boundary is the step barrier.
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 template <int H>
 __global__ __launch_bounds__(256) void lstm_step_kernel(const float *__restrict__ gx, const float *__restrict__ whh,
@@ -210,82 +212,154 @@ int launch_lstm_seq(const float *gx, const float *whh, int N, int H, int W, floa
 }
 
 // ---- LocalState attention (demucs/demucs.py:182-216) ------------------------------------------------------------------
-// qkc (B, 3C + 16, T): rows [0, C) queries, [C, 2C) keys, [2C, 3C) content, [3C, 3C + 16) decay logits (heads x 4).
-// For query s of head h:  score(t) = k_t . q_s / sqrt(dh) - |t - s| * slope_s,  slope_s = sum_f (f + 1) * (sigmoid(d_f) / 2) / 2,
-// score(s) = -100, softmax over t, out[c][s] = sum_t w_t content[c][t].
-// Workgroup = 8 queries x 8 key lanes: lane kl of a query takes keys kl, kl + 8, ... of every 64-key LDS tile with its own
-// online-softmax state; the 8 states of a query are merged with lane shuffles at the end (flash-decoding style split).
+// qkc (B, 3C + 16, ld): rows [0, C) queries, [C, 2C) keys, [2C, 3C) content, [3C, 3C + 16) decay logits (heads x 4); the row
+// pitch ld is a multiple of 4 (>= T).  For query s of head h:
+//     score(t) = k_t . q_s / sqrt(dh) - |t - s| * slope_s,  slope_s = sum_f (f + 1) * (sigmoid(d_f) / 2) / 2,  score(s) = -100,
+// softmax over t, out[c][s] = sum_t w_t content[c][t].
+// Flash attention on the float32 matrix pipe, the scheme of attention.hip: a wave owns 32 queries and computes the TRANSPOSED
+// score tile S^T[key][query] = K^T Q per 32 keys (keys on MFMA rows, queries on lanes), adds the distance penalty and the
+// diagonal fill in registers, and after the online softmax its 16 accumulator registers ARE the B operand of
+// O^T[d][query] += content[d][key] P^T[key][query].  Workgroup = 2 waves = 64 queries sharing the K / content LDS tiles
+// (64 keys); DH = 48 runs its output product on two 32-row tiles with rows 48..63 zero.
 template <int DH>
-__global__ __launch_bounds__(64) void local_attn_kernel(const float *__restrict__ qkc, int C, int T, float *__restrict__ out) {
-    constexpr int KT = 64;
-    __shared__ float ks[KT][DH + 1], cs[KT][DH + 1];
-    const int b = blockIdx.z, h = blockIdx.y, ql = threadIdx.x >> 3, kl = threadIdx.x & 7;
-    const int s = blockIdx.x * 8 + ql;
-    const int rows = 3 * C + 16;
-    const float *base = qkc + (size_t)b * rows * T;
-    const bool ok = s < T;
-    const int sq = ok ? s : 0;
-    float q[DH], acc[DH];
+__global__ __launch_bounds__(128) void local_attn_kernel(const float *__restrict__ qkc, int C, int T, int ld, float *__restrict__ out,
+                                                         int ld_o) {
+    constexpr int KT = 64, VLD = KT + 1, ND = (DH + 31) / 32, HD = ND * 32, NS = DH / 2;
+    __shared__ float Ks[DH][KT];
+    __shared__ float Vs[HD][VLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+    const int head = blockIdx.y, b = blockIdx.z;
+    const int q0 = blockIdx.x * 64 + wave * 32;
+    const float *base = qkc + (size_t)b * (3 * C + 16) * ld;
+    const float *qp = base + (size_t)head * DH * ld, *kp = base + (size_t)(C + head * DH) * ld,
+                *vp = base + (size_t)(2 * C + head * DH) * ld, *dp = base + (size_t)(3 * C + head * 4) * ld;
+    const int qi = q0 + li;
+    const bool qok = qi < T;
     const float isq = 1.0f / sqrtf((float)DH);
+    float qreg[NS];                                       // B operand of S^T: lane (query li, half lh) holds Q[d = 2 s + lh][qi] / sqrt(dh)
 #pragma unroll
-    for (int d = 0; d < DH; ++d) { q[d] = base[(size_t)(h * DH + d) * T + sq] * isq; acc[d] = 0.f; }
+    for (int s = 0; s < NS; ++s) qreg[s] = qok ? qp[(size_t)(2 * s + lh) * ld + qi] * isq : 0.f;
     float slope = 0.f;
+    if (qok) {
 #pragma unroll
-    for (int f = 0; f < 4; ++f) slope += (float)(f + 1) * (sigmoid_f(base[(size_t)(3 * C + h * 4 + f) * T + sq]) * 0.5f);
-    slope *= 0.5f;                                           // / ndecay ** 0.5
-    float m = -INFINITY, l = 0.f;
-    for (int t0 = 0; t0 < T; t0 += KT) {
-        __syncthreads();
-        for (int i = threadIdx.x; i < KT * DH; i += 64) {
-            const int d = i / KT, tt = i % KT, t = t0 + tt;
-            ks[tt][d] = t < T ? base[(size_t)(C + h * DH + d) * T + t] : 0.f;
-            cs[tt][d] = t < T ? base[(size_t)(2 * C + h * DH + d) * T + t] : 0.f;
-        }
-        __syncthreads();
-#pragma unroll 2
-        for (int tt = kl; tt < KT; tt += 8) {
-            const int t = t0 + tt;
-            if (t >= T) break;
-            float sc = 0.f;
+        for (int f = 0; f < 4; ++f) slope += (float)(f + 1) * (sigmoid_f(dp[(size_t)f * ld + qi]) * 0.5f);
+    }
+    slope *= 0.5f;                                        // / ndecay ** 0.5
+    f32x16 oacc[ND];
 #pragma unroll
-            for (int d = 0; d < DH; ++d) sc = fmaf(ks[tt][d], q[d], sc);
-            sc -= fabsf((float)(t - s)) * slope;
-            if (t == s) sc = -100.f;
-            if (sc > m) {
-                const float a = expf(m - sc);
-                l *= a;
+    for (int dt = 0; dt < ND; ++dt)
 #pragma unroll
-                for (int d = 0; d < DH; ++d) acc[d] *= a;
-                m = sc;
+        for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
+    float mrun = -INFINITY, lrun = 0.f;
+    if (HD > DH) {                                        // zero rows of the padded content tile, written once
+        for (int i = tid; i < (HD - DH) * VLD; i += 128) (&Vs[DH][0])[i] = 0.f;
+    }
+    const int sr = tid >> 4, sc4 = (tid & 15) * 4;        // tile loads: rows sr + 8 it, columns sc4 .. sc4 + 3
+    for (int k0 = 0; k0 < T; k0 += KT) {
+        __syncthreads();                                  // previous tile fully consumed
+#pragma unroll 4
+        for (int r = sr; r < DH; r += 8) {
+            float4 kk = make_float4(0.f, 0.f, 0.f, 0.f), vv = kk;
+            if (k0 + sc4 + 3 < T) {
+                kk = *reinterpret_cast<const float4 *>(kp + (size_t)r * ld + k0 + sc4);
+                vv = *reinterpret_cast<const float4 *>(vp + (size_t)r * ld + k0 + sc4);
+            } else {                                      // ragged end: the pitch padding holds no defined values
+                float tk[4] = {0.f, 0.f, 0.f, 0.f}, tv[4] = {0.f, 0.f, 0.f, 0.f};
+                for (int e = 0; e < 4; ++e)
+                    if (k0 + sc4 + e < T) { tk[e] = kp[(size_t)r * ld + k0 + sc4 + e]; tv[e] = vp[(size_t)r * ld + k0 + sc4 + e]; }
+                kk = make_float4(tk[0], tk[1], tk[2], tk[3]); vv = make_float4(tv[0], tv[1], tv[2], tv[3]);
             }
-            const float p = expf(sc - m);
-            l += p;
+            *reinterpret_cast<float4 *>(&Ks[r][sc4]) = kk;
+            Vs[r][sc4] = vv.x; Vs[r][sc4 + 1] = vv.y; Vs[r][sc4 + 2] = vv.z; Vs[r][sc4 + 3] = vv.w;
+        }
+        __syncthreads();
 #pragma unroll
-            for (int d = 0; d < DH; ++d) acc[d] = fmaf(p, cs[tt][d], acc[d]);
+        for (int sub = 0; sub < 2; ++sub) {
+            const int kb = sub * 32;
+            if (k0 + kb >= T) break;                      // workgroup-uniform
+            f32x16 sacc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+            float kf[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) kf[s] = Ks[2 * s + lh][kb + li];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const float a = kf[s & 3];
+                if (s + 4 < NS) kf[s & 3] = Ks[2 * (s + 4) + lh][kb + li];
+                sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, qreg[s], sacc, 0, 0, 0);
+            }
+            float vf[ND][4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int kc = kb + (s & 3) + 8 * (s >> 2) + 4 * lh;
+#pragma unroll
+                for (int dt = 0; dt < ND; ++dt) vf[dt][s] = Vs[dt * 32 + li][kc];
+            }
+            // register r of lane (li, lh) is key k0 + kb + (r & 3) + 8 (r >> 2) + 4 lh, query qi
+            float mloc = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int t = k0 + kb + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                float sc = sacc[r] - fabsf((float)(t - qi)) * slope;
+                if (t == qi) sc = -100.f;
+                if (t >= T) sc = -INFINITY;
+                sacc[r] = sc;
+                mloc = fmaxf(mloc, sc);
+            }
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+            const float mnew = fmaxf(mrun, mloc);
+            float psum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __expf(sacc[r] - mnew);
+                sacc[r] = p;
+                psum += p;
+            }
+            if (__any(mnew != mrun)) {
+                const float alpha = __expf(mrun - mnew);  // exp(-inf) = 0 on the first tile
+                lrun *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+                mrun = mnew;
+            }
+            lrun += psum;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                float a[ND];
+#pragma unroll
+                for (int dt = 0; dt < ND; ++dt) a[dt] = vf[dt][s & 3];
+                if (s + 4 < 16) {
+                    const int kc = kb + ((s + 4) & 3) + 8 * ((s + 4) >> 2) + 4 * lh;
+#pragma unroll
+                    for (int dt = 0; dt < ND; ++dt) vf[dt][s & 3] = Vs[dt * 32 + li][kc];
+                }
+#pragma unroll
+                for (int dt = 0; dt < ND; ++dt) oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[dt], sacc[s], oacc[dt], 0, 0, 0);
+            }
         }
     }
-    // merge the 8 key-lane states of the query (lanes kl = 0..7 are adjacent)
+    const float ltot = lrun + __shfl_xor(lrun, 32);
+    const float inv = 1.0f / ltot;
+    if (qok) {
+        float *op = out + ((size_t)b * C + head * DH) * ld_o + qi;
 #pragma unroll
-    for (int off = 1; off < 8; off <<= 1) {
-        const float mo = __shfl_xor(m, off), lo = __shfl_xor(l, off);
-        const float mn = fmaxf(m, mo);
-        const float a = mn == -INFINITY ? 0.f : expf(m - mn), bb = mn == -INFINITY ? 0.f : expf(mo - mn);
-        l = l * a + lo * bb;
+        for (int dt = 0; dt < ND; ++dt)
 #pragma unroll
-        for (int d = 0; d < DH; ++d) acc[d] = acc[d] * a + __shfl_xor(acc[d], off) * bb;
-        m = mn;
-    }
-    if (ok && kl == 0) {
-        const float inv = 1.0f / l;
-#pragma unroll
-        for (int d = 0; d < DH; ++d) out[((size_t)b * C + h * DH + d) * T + s] = acc[d] * inv;
+            for (int r = 0; r < 16; ++r) {
+                const int dd = dt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (dd < DH) op[(size_t)dd * ld_o] = oacc[dt][r] * inv;
+            }
     }
 }
 
-int launch_local_attn(const float *qkc, int B, int C, int T, float *out, hipStream_t st) {
-    const dim3 grid(ceil_div(T, 8), 4, B);
-    if (C == 192) hipLaunchKernelGGL(local_attn_kernel<48>, grid, dim3(64), 0, st, qkc, C, T, out);
-    else if (C == 384) hipLaunchKernelGGL(local_attn_kernel<96>, grid, dim3(64), 0, st, qkc, C, T, out);
+int launch_local_attn(const float *qkc, int B, int C, int T, int ld, float *out, int ld_o, hipStream_t st) {
+    MI_REQUIRE(ld % 4 == 0 && ld >= T && ((uintptr_t)qkc & 15) == 0, "local_attn: row pitch %d must be a multiple of 4 (T = %d)", ld, T);
+    const dim3 grid(ceil_div(T, 64), 4, B);
+    if (C == 192) hipLaunchKernelGGL(local_attn_kernel<48>, grid, dim3(128), 0, st, qkc, C, T, ld, out, ld_o);
+    else if (C == 384) hipLaunchKernelGGL(local_attn_kernel<96>, grid, dim3(128), 0, st, qkc, C, T, ld, out, ld_o);
     else return set_error(MI_EINVAL, "local_attn: %d channels not instantiated", C);
     MI_CHECK_LAUNCH();
     return MI_OK;

@@ -331,9 +331,10 @@ int HModel::run_deep(HGeo &g, HEncW &e, int C, int Tn, int B, float *x, float *t
         // ---- LocalState(hidden, heads = 4, ndecay = 4) --------------------------------------------------------------
         MI_TRY(ktab(g, Gather{H, 1, 1, 1, 1, 0, 0, (int64_t)Tn, Tn}, l.qkc.Kpad, &k));
         mi_conv_desc q = base_desc(l.qkc, k, x_dy2, (int64_t)H * Tn, gt);
-        q.plain = 1; q.epi = MI_EPI_LINEAR; q.y = x_qkc; q.y_bstride = (int64_t)(3 * H + 16) * Tn; q.y_cstride = Tn;
+        const int Tq = round_up(Tn, 4);                  // row pitch of the projection: 16-byte aligned key / content rows
+        q.plain = 1; q.epi = MI_EPI_LINEAR; q.y = x_qkc; q.y_bstride = (int64_t)(3 * H + 16) * Tq; q.y_cstride = Tq;
         MI_TRY(conv(q, st));
-        MI_TRY(launch_local_attn(x_qkc, B, H, Tn, x_att, st));
+        MI_TRY(launch_local_attn(x_qkc, B, H, Tn, Tq, x_att, Tn, st));
         mi_conv_desc pj = base_desc(l.proj, k, x_att, (int64_t)H * Tn, gt);
         pj.plain = 1; pj.epi = MI_EPI_LINEAR; pj.flags = MI_FLAG_RES; pj.res = x_dy2; pj.y = x_dy3; pj.y_bstride = (int64_t)H * Tn; pj.y_cstride = Tn;
         MI_TRY(conv(pj, st));
