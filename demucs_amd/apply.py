@@ -380,7 +380,8 @@ def device_split_accumulate(model: HTDemucs, base: torch.Tensor, chunk_offset: i
     padded windows touch, or the real track end.
     `on_start(offset)` / `on_end(offset)` bracket each segment's forward in the reference's event order
     (start, end, start, end ...): the first `start` of a batch fires before the batched forward is
-    enqueued and no `end` fires before it."""
+    enqueued and no `end` fires before the batch has been COMPUTED (the stream is synchronised first when an `end`
+    listener exists; without one nothing waits)."""
     if valid_length > model.segment_length:
         raise ValueError(f"Given length {valid_length} is longer than training length {model.segment_length}")
     if segment_length > valid_length or weight.numel() < segment_length:
@@ -414,6 +415,8 @@ def device_split_accumulate(model: HTDemucs, base: torch.Tensor, chunk_offset: i
             if on_start is not None:
                 on_start(offs[0])
             model.forward_segments(seg_buf[:nb], out_buf[:nb])
+            if on_end is not None:
+                torch.cuda.current_stream(dev).synchronize()      # "end" means computed, as after the reference's blocking leaf
             for k, o in enumerate(offs):
                 if draw_rng:
                     random.randrange(1)              # transformer.py:680, once per segment forward (whole batch of tracks)
@@ -463,6 +466,8 @@ def ragged_split_accumulate(model: HDemucs, base: torch.Tensor, chunk_offset: in
             if on_start is not None:
                 on_start(offs[0])
             out = model(seg)
+            if on_end is not None:
+                torch.cuda.current_stream(dev).synchronize()      # "end" means computed
             for k, o in enumerate(offs):
                 if k and on_start is not None:
                     on_start(o)

@@ -194,3 +194,22 @@ def test_separator_tensor_contract():
         sep.separate_tensor(wav, sr=48000)
     with pytest.raises(LoadModelError):
         Separator("htdemucs")
+
+
+def test_device_scheduler_refuses_oversized_windows_before_any_launch():
+    """`device_split_accumulate` sizes its segment buffer for `model.segment_length`: a padded window longer than that
+    (a segment override above the training length, demucs/apply.py:305-310 -> htdemucs.py:531-533 raises there too) or a
+    weight ramp shorter than a segment must be refused on the host, before the library is even loaded -- the gather
+    kernel would otherwise write past the buffer.  Runs without a GPU: the checks come first."""
+    class Stub:
+        segment_length, max_batch, samplerate, sources = 1000, 4, 44100, ["a"]
+
+    base, acc, w = torch.zeros(2, 5000), torch.zeros(2, 5000), torch.ones(1000)
+    with pytest.raises(ValueError, match="longer than training length"):
+        P.device_split_accumulate(Stub(), base, 0, 5000, [0, 750], 1000, 1200, w, acc, 0)
+    with pytest.raises(ValueError, match="does not fit"):
+        P.device_split_accumulate(Stub(), base, 0, 5000, [0, 750], 1000, 900, w, acc, 0)
+    with pytest.raises(ValueError, match="does not fit"):
+        P.device_split_accumulate(Stub(), base, 0, 5000, [0, 750], 1000, 1000, torch.ones(10), acc, 0)
+    with pytest.raises(ValueError, match="weight ramp"):
+        P.ragged_split_accumulate(Stub(), base, 0, 5000, [0, 750], 1000, torch.ones(10), acc)
