@@ -86,6 +86,29 @@ def test_full_resolution_vs_float64_oracle_and_batching():
     assert torch.equal(single[0], out[1])
 
 
+def test_many_sequences_span_several_lstm_tiles():
+    """A batch of 7 items of 23.3 s: the BLSTM of encoder.4 sees 7 x 11 = 77 framed sequences (sequence tiles of 32, 32
+    and 13 in `lstm_step_kernel`), encoder.5's 7 x 6 = 42 (32 + 10), and LocalState runs over 1 004 / 502 positions with
+    a ragged last key tile -- the geometry of the 44-second production chunks, checked sample by sample against the
+    float64 oracle (the 4-second cases above stay inside one tile)."""
+    from demucs_amd.hdemucs_weights import hdemucs_layer_plan
+    from oracle import hdemucs_oracle as HO
+    cfg = HDemucsConfig()
+    sd = synthetic_hdemucs_state_dict(cfg, 5)
+    B, L = 7, 1027600
+    m = HDemucs(cfg.sources, max_batch=B)
+    m.load_state_dict(sd)
+    m.to("cuda")
+    mix = torch.stack([torch.from_numpy(synth_mix(60 + b, L, "tones" if b % 2 else "noise")) for b in range(B)])
+    out = m(mix.cuda()).cpu()
+    osd = {k: torch.from_numpy(v.copy()).double() for k, v in sd.items()}
+    with torch.no_grad():
+        want = HO.hdemucs_forward(osd, mix.double(), hdemucs_layer_plan(cfg), 4)
+    err = (out.double() - want).abs().amax(dim=(1, 2, 3))
+    print(f"hdemucs 7 x 23.3 s: per-item max-abs {[f'{e:.2e}' for e in err.tolist()]} (out rms {want.pow(2).mean().sqrt():.3f})")
+    assert float(err.max()) <= TOL
+
+
 @pytest.mark.parametrize("max_batch", [1, 2])
 def test_apply_model_matches_reference(golden, max_batch):
     """`apply_model` around the engine with a segment override: three chunks of 176 400 samples and a last one of 52 933,
