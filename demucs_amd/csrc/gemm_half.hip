@@ -111,6 +111,13 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_half_kernel(const mi_conv_de
     // latency bound otherwise: one 24 KiB tile per workgroup in flight keeps the L2 at ~10 TB/s and the matrix pipe at 11 %)
     uint4 areg0 = make_uint4(0, 0, 0, 0), areg1 = areg0, areg2 = areg0, areg3 = areg0;      // weights (L2 resident) and gathered activations: one step ahead
     float breg[1][16];
+    // the gather table through the constant address space: the entries of a K step are wave-uniform, and only loads the
+    // compiler can prove invariant become scalar (s_load) -- as per-lane loads they put a second dependent memory round
+    // trip in front of every activation load
+    typedef int ktab_i4 __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(4))) ktab_i4 *ktab_ptr;
+    static_assert(sizeof(mi_ktab_entry) == 16, "gather table entry = 4 dwords (off, d1, d2, ci)");
+    const ktab_ptr ktab_c = (ktab_ptr)(uintptr_t)d.ktab;
     // PLAIN (1x1 / linear, channel stride P, P % 4 == 0): thread = (column quad q, pair group pg) loads rows 2 pg, 2 pg + 1,
     // 16 + 2 pg, 17 + 2 pg of the K step as float4 along n (4 VMEM instructions instead of 16 dword loads), packs the two
     // rows of a pair per column and writes ONE 16-byte word per pair into the pair-interleaved image
@@ -134,7 +141,10 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_half_kernel(const mi_conv_de
         } else {                                                                                      \
             _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                           \
                 mi_ktab_entry ke[8];                                                                  \
-                _Pragma("unroll") for (int j = 0; j < 8; ++j) ke[j] = d.ktab[(kt) * HK + 16 * bh + 8 * h + j]; \
+                _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                       \
+                    const ktab_i4 e4 = ktab_c[(kt) * HK + 16 * bh + 8 * h + j];                       \
+                    ke[j].off = e4.x; ke[j].d1 = e4.y; ke[j].d2 = e4.z; ke[j].ci = e4.w;              \
+                }                                                                                     \
                 _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                       \
                     bool ok;                                                                          \
                     const float v = gather_b(d, ke[j], xcol, i1b, i2b, lc.valid, ok);                 \
