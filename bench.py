@@ -121,11 +121,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    # engine handle, weight images and workspace are built by the first forward: do that on a 10-second clip, outside any
-    # timed region even when --warmup 0 is asked for (single-process, no collective)
-    from demucs_amd.distributed import no_sharding
-    with no_sharding():
-        P.apply_model(model, make_mix(10), shifts=0, split=True, overlap=0.25, device=dev)
+    # engine handle, weight images and workspace are built by the first forward: with --warmup 0 do that on a 10-second
+    # clip, outside the timed region (single-process, no collective)
+    if args.warmup == 0:
+        from demucs_amd.distributed import no_sharding
+        with no_sharding():
+            P.apply_model(model, make_mix(10), shifts=0, split=True, overlap=0.25, device=dev)
     mix = make_mix(seconds)                                             # synthetic, resident in HBM
     length = mix.shape[-1]
     n_segments = len(range(0, length, stride))
