@@ -80,6 +80,11 @@ SIGNATURES = {
                                C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_void_p]),
     "mi_gn_gelu": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                              C.c_void_p, C.c_void_p]),
+    "mi_gram_order": (C.c_int32, [C.c_int32]),
+    "mi_gn_gelu_gram": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "mi_gram_finalize": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_double, C.c_double,
+                                   C.c_double, C.c_double, C.c_float, C.c_void_p, C.c_void_p]),
     "mi_layernorm_cf": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p]),
     "mi_debug_set_post_launch_hook": (None, [C.c_void_p]),

@@ -278,6 +278,23 @@ int mi_gn_gelu(float *x_dev, int32_t B, int32_t C, int32_t C_alloc, int32_t D1, 
     return launch_gn_gelu(x_dev, B, C, C_alloc, D1, D2, row_mode, (const float2 *)stats_dev, w_dev, b_dev, (hipStream_t)stream);
 }
 
+int32_t mi_gram_order(int32_t h) { return gram_hp(h); }
+
+int mi_gn_gelu_gram(float *x_dev, int32_t B, int32_t h, int32_t C_alloc, int32_t D1, int32_t D2, int32_t pitch, int32_t row_mode,
+                    const float *stats_dev, const float *w_dev, const float *b_dev, double *gram_dev, int32_t slots, void *stream) {
+    MI_REQUIRE(x_dev && stats_dev && w_dev && b_dev && gram_dev && B > 0 && h > 0 && D1 > 0 && D2 > 0 && slots > 0, "mi_gn_gelu_gram: bad argument");
+    MI_REQUIRE(C_alloc >= h && pitch >= D2, "mi_gn_gelu_gram: C_alloc < h or pitch < D2");
+    return launch_gn_gelu_gram(x_dev, B, h, C_alloc, D1, D2, pitch, row_mode, (const float2 *)stats_dev, w_dev, b_dev, gram_dev, slots,
+                               (hipStream_t)stream);
+}
+
+int mi_gram_finalize(double *gram_dev, int32_t rows, int32_t h, int32_t slots, const double *wt_dev, const double *ct_dev, double sum_b,
+                     double sum_bsq, double cols, double count, float eps, float *stats_out_dev, void *stream) {
+    MI_REQUIRE(gram_dev && wt_dev && ct_dev && stats_out_dev && rows > 0 && h > 0 && slots > 0 && count > 0.0, "mi_gram_finalize: bad argument");
+    return launch_gram_finalize(gram_dev, rows, h, slots, wt_dev, ct_dev, sum_b, sum_bsq, cols, count, eps, (float2 *)stats_out_dev,
+                                (hipStream_t)stream);
+}
+
 int mi_layernorm_cf(const float *x_dev, int32_t B, int32_t C, int32_t T, const float *w_dev, const float *b_dev,
                     const float *add_dev, float *y_dev, void *stream) {
     MI_REQUIRE(x_dev && w_dev && b_dev && y_dev, "mi_layernorm_cf: null argument");

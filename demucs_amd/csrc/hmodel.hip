@@ -220,6 +220,9 @@ int HModel::hinit(const mi_config &c, const mi_tensor_desc *weights, size_t n) {
     x_stats_bytes = max_rows * kStatSlots * 2 * sizeof(double);
     MI_TRY(halloc((void **)&x_stats, x_stats_bytes)); MI_TRY(halloc((void **)&x_stats_t, x_stats_bytes));
     MI_HIP(hipMemset(x_stats, 0, x_stats_bytes)); MI_HIP(hipMemset(x_stats_t, 0, x_stats_bytes));
+    gram2_bytes = B * ((size_t)4 << 20);                  // Model::run_dconv's Gram accumulators: B x 512 rows x 32 x 32 float64 at layer 0
+    MI_TRY(halloc((void **)&w_gram2, gram2_bytes));
+    MI_HIP(hipMemset(w_gram2, 0, gram2_bytes));
     MI_TRY(halloc((void **)&x_st1, max_rows * sizeof(float2))); MI_TRY(halloc((void **)&x_st2, max_rows * sizeof(float2)));
     MI_TRY(halloc((void **)&x_st1t, max_rows * sizeof(float2))); MI_TRY(halloc((void **)&x_st2t, max_rows * sizeof(float2)));
     MI_TRY(halloc((void **)&x_nf, B * sizeof(float2))); MI_TRY(halloc((void **)&x_df, B * sizeof(float2)));
@@ -352,6 +355,7 @@ int HModel::hforward(const float *mix, float *out, int B, int L, hipStream_t st)
     if (x_dirty) {
         MI_HIP(hipMemsetAsync(x_stats, 0, x_stats_bytes, st));
         MI_HIP(hipMemsetAsync(x_stats_t, 0, x_stats_bytes, st));
+        MI_HIP(hipMemsetAsync(w_gram2, 0, gram2_bytes, st));
         x_dirty = false;
     }
     const int r = hforward_impl(mix, out, B, L, st);

@@ -32,6 +32,12 @@ int launch_token_stats(const float *x, int B, int C, int T, float2 *ostat, hipSt
 int launch_gn_apply_tokstats(const float *x, int B, int C, int T, const float2 *gstat, const float *w, const float *b, float *y,
                              float2 *ostat, hipStream_t st);
 
+// GroupNorm(1) + GELU in place plus the Gram accumulators that give the NEXT GroupNorm's statistics (norms.hip)
+int gram_hp(int h);          // accumulator matrix order for h hidden channels: h + 1 rounded up to 32
+int launch_gn_gelu_gram(float *x, int B, int h, int Cs, int D1, int D2 /* valid */, int pitch, int row_mode, const float2 *stats, const float *w,
+                        const float *b, double *gram /* rows x slots x HP x HP, zero */, int slots, hipStream_t st);
+int launch_gram_finalize(double *gram, int rows, int h, int slots, const double *wt /* HP x HP */, const double *ct /* HP */, double sum_b,
+                         double sum_bsq, double cols, double count, float eps, float2 *out, hipStream_t st);
 int launch_gn_gelu(float *x, int B, int C, int Cs, int D1, int D2, int row_mode, const float2 *stats, const float *w, const float *b,
                    hipStream_t st);
 

@@ -25,6 +25,9 @@ struct DConvLayerW {
     PackedConv conv3, conv1;
     mi_ktab_entry *ktab3 = nullptr, *ktab1 = nullptr;
     float *gn1_w = nullptr, *gn1_b = nullptr, *gn2_w = nullptr, *gn2_b = nullptr, *ls = nullptr;
+    // implicit-GEMM route: weights that turn the Gram accumulators of the hidden activations into the second GroupNorm's
+    // statistics (norms.hip: gram_finalize_kernel)
+    double *gram_wt = nullptr, *gram_ct = nullptr, sum_b = 0.0, sum_bsq = 0.0;
 };
 struct DConvW {
     DConvLayerW l[2];
@@ -85,7 +88,8 @@ struct WorkspacePtrs {
     float *w_tr_x[2][2] = {}, *w_tr_qkv[2] = {}, *w_tr_att[2] = {}, *w_tr_x1[2] = {},
           *w_tr_x2[2] = {}, *w_tr_ffh[2] = {};
     float *w_yspec = nullptr, *w_ytime = nullptr, *w_yt = nullptr, *w_fr = nullptr;
-    double *w_stats = nullptr, *w_stats_t = nullptr, *w_gram = nullptr;
+    double *w_stats = nullptr, *w_stats_t = nullptr, *w_gram = nullptr, *w_gram2 = nullptr;
+    size_t gram2_bytes = 0;      // w_gram2: Gram accumulators of the implicit-GEMM DConv route (rows x slots x HP x HP float64)
     float2 *w_st1 = nullptr, *w_st2 = nullptr, *w_st1_t = nullptr, *w_st2_t = nullptr;
     float2 *w_norm_f = nullptr, *w_denorm_f = nullptr, *w_norm_t = nullptr, *w_denorm_t = nullptr;
 };

@@ -254,6 +254,27 @@ int Model::load_dconv(const WeightTable &wt, const std::string &prefix, int C, i
         MI_TRY(pack_vec(g2w, 2 * C, l.conv1.Mpad, true, &l.gn2_w));
         MI_TRY(pack_vec(g2b, 2 * C, l.conv1.Mpad, true, &l.gn2_b));
         MI_TRY(pack_vec(ls, C, C, false, &l.ls));
+        {   // implicit-GEMM route: sum z^2 = <wt, G>, sum z = ct . G[:, h] over the accumulators of gn_gelu_gram_kernel (entries of
+            // the upper block triangle; blocks above the diagonal count twice; column h of G holds sum g)
+            const int HP = gram_hp(h);
+            std::vector<double> gw((size_t)HP * HP, 0.0), gc(HP, 0.0);
+            double sb = 0.0, sbq = 0.0;
+            for (int m = 0; m < 2 * C; ++m) { sb += (double)b3[m]; sbq += (double)b3[m] * (double)b3[m]; }
+            for (int i = 0; i < h; ++i) {
+                for (int k = 0; k < h; ++k) {
+                    if ((k >> 5) < (i >> 5)) continue;
+                    double a = 0.0;
+                    for (int m = 0; m < 2 * C; ++m) a += (double)w3[(size_t)m * h + i] * (double)w3[(size_t)m * h + k];
+                    gw[(size_t)i * HP + k] = (k >> 5) > (i >> 5) ? 2.0 * a : a;
+                }
+                double v = 0.0, c1 = 0.0;
+                for (int m = 0; m < 2 * C; ++m) { v += 2.0 * (double)w3[(size_t)m * h + i] * (double)b3[m]; c1 += (double)w3[(size_t)m * h + i]; }
+                gw[(size_t)i * HP + h] = v;
+                gc[i] = c1;
+            }
+            MI_TRY(upload(gw, &l.gram_wt)); MI_TRY(upload(gc, &l.gram_ct));
+            l.sum_b = sb; l.sum_bsq = sbq;
+        }
         if (dw->has_row || dw->has_time) {          // packing of dconv_row.hip / dconv_time.hip: hidden index fastest, padded to a multiple of 4
             const int HA = (h + 3) / 4 * 4;
             std::vector<float> w0r((size_t)C * 3 * HA, 0.f), b0r(HA, 0.f), g1wr(HA, 0.f), g1br(HA, 0.f), w3r((size_t)2 * C * HA, 0.f);
@@ -562,6 +583,9 @@ int Model::fill_workspace(Workspace &w) {
     w.gram_bytes = B * kStatSlots * 96 * sizeof(double);          // dconv_time.hip: kGramMax doubles per slot
     MI_TRY(dev_alloc((void **)&w.w_gram, w.gram_bytes));
     MI_HIP(hipMemset(w.w_gram, 0, w.gram_bytes));
+    w.gram2_bytes = B * ((size_t)4 << 20);                         // B x 512 rows x 32 x 32 float64 is the largest user
+    MI_TRY(dev_alloc((void **)&w.w_gram2, w.gram2_bytes));
+    MI_HIP(hipMemset(w.w_gram2, 0, w.gram2_bytes));
     MI_HIP(hipMemset(w.w_stats, 0, w.stats_bytes));      // finalize_stats re-zeroes after each use
     MI_HIP(hipMemset(w.w_stats_t, 0, w.stats_bytes));
     MI_TRY(dev_alloc((void **)&w.w_st1, max_rows * sizeof(float2)));
@@ -636,12 +660,15 @@ int Model::run_dconv(const DConvW &w, int C, const Geo &g, float *x, float *tmp,
         d.epi = MI_EPI_BIAS_STATS; d.y = hidden; d.y_bstride = (int64_t)hp * P; d.y_cstride = P; d.stats = stats;
         MI_TRY(conv(d, st));
         MI_TRY(launch_finalize_stats(stats, rows, cnt_row * h, 1e-5f, 0, st1, nullptr, st));
-        MI_TRY(launch_gn_gelu(hidden, g.B, h, hp, g.D1, g.pitch(), g.row_mode, st1, l.gn1_w, l.gn1_b, st));
+        // GroupNorm + GELU of the hidden tensor in place, and in the same pass the Gram sums from which the second GroupNorm's
+        // statistics follow (no statistics-only evaluation of the 2C x h GEMM)
+        const int gslots = g.row_mode ? 1 : 8, HP = gram_hp(h);
+        MI_REQUIRE((size_t)rows * gslots * HP * HP * sizeof(double) <= gram2_bytes, "dconv: Gram accumulators need %zu bytes, workspace has %zu",
+                   (size_t)rows * gslots * HP * HP * sizeof(double), gram2_bytes);
+        MI_TRY(launch_gn_gelu_gram(hidden, g.B, h, hp, g.D1, g.D2, g.pitch(), g.row_mode, st1, l.gn1_w, l.gn1_b, w_gram2, gslots, st));
+        MI_TRY(launch_gram_finalize(w_gram2, rows, h, gslots, l.gram_wt, l.gram_ct, l.sum_b, l.sum_bsq, cnt_row, cnt_row * 2 * C, 1e-5f, st2, st));
         mi_conv_desc e = base_desc(l.conv1, l.ktab1, hidden, (int64_t)hp * P, g);
         e.plain = 1;
-        e.epi = MI_EPI_STATS_ONLY; e.stats = stats;
-        MI_TRY(conv(e, st));
-        MI_TRY(launch_finalize_stats(stats, rows, cnt_row * 2 * C, 1e-5f, 0, st2, nullptr, st));
         e.epi = MI_EPI_GN_GLU; e.stats = nullptr; e.gn_stats = (const float *)st2; e.gn_w = l.gn2_w; e.gn_b = l.gn2_b;
         e.scale = l.ls; e.res = src; e.y = dst; e.y_bstride = (int64_t)C * P; e.y_cstride = P;
         MI_TRY(conv(e, st));
@@ -717,6 +744,7 @@ int Model::run_core(const float *mix, const float *mag, int B, hipStream_t st) {
         MI_HIP(hipMemsetAsync(w_stats, 0, ws->stats_bytes, st));
         MI_HIP(hipMemsetAsync(w_stats_t, 0, ws->stats_bytes, st));
         MI_HIP(hipMemsetAsync(w_gram, 0, ws->gram_bytes, st));
+        MI_HIP(hipMemsetAsync(w_gram2, 0, gram2_bytes, st));
         ws->dirty = false;
     }
     const int r = run_core_impl(mix, mag, B, st);

@@ -170,6 +170,130 @@ int launch_gn_gelu(float *x, int B, int C, int Cs, int D1, int D2, int row_mode,
     return MI_OK;
 }
 
+// ---- DConv (implicit-GEMM route): GroupNorm(1) + GELU of the hidden tensor AND the second GroupNorm's statistics ------
+// The 1x1 conv that follows, z = W g + b over 2C channels, is normalised by GroupNorm(1, 2C) (demucs.py:141-142), whose
+// statistics over a row's columns follow from  s = sum g  and  G = sum g g^T  (h x h, h = C / 8 or C / 4):
+//     sum z = colsum(W) . s + n sum b,      sum z^2 = <W^T W, G> + 2 (W^T b) . s + n sum b^2.
+// One pass instead of a statistics-only evaluation of the 2C x h GEMM: this kernel normalises 128 columns of a row in
+// place, keeps them as an LDS tile Gs[HP][128 or 64] (row h = ones, so G[.][h] = s; rows above are zero) and forms the tile's
+// Gram blocks on the float32 matrix pipe (v_mfma_f32_32x32x2_f32: exact products), upper block triangle only, added
+// to the row's float64 accumulators.  grid (ceil(cols / column tile), rows); HP = h + 1 rounded up to 32.
+typedef float gram_f32x16 __attribute__((ext_vector_type(16)));
+template <int HP>
+__global__ __launch_bounds__(256) void gn_gelu_gram_kernel(float *__restrict__ x, int h, int Cs, int D1, int D2, int pitch, int row_mode,
+                                                           const float2 *__restrict__ st, const float *__restrict__ w,
+                                                           const float *__restrict__ bvec, double *__restrict__ gram, int slots) {
+    constexpr int CT = HP > 96 ? 64 : 128, CG = 256 / CT, LDG = CT + 1, NT = HP / 32;      // column tile: <= 48 KiB of LDS
+    __shared__ float Gs[HP][LDG];
+    const int tid = threadIdx.x, row = blockIdx.y, col = tid & (CT - 1), cg = tid / CT;
+    const int b = row_mode ? row / D1 : row, d1 = row_mode ? row % D1 : 0;
+    const int cols = row_mode ? D2 : D1 * D2;                    // valid columns of a statistics row (time branch: D1 == 1)
+    const int q = blockIdx.x * CT + col;
+    const bool ok = q < cols;
+    const float2 s = st[row];
+    float *xp = x + (size_t)b * Cs * D1 * pitch + (size_t)d1 * pitch + q;
+    // all loads first: a load after a store into the same tensor is not hoisted above it, and the chain of round trips
+    // would cost more than the statistics GEMM this pass replaces
+    float v[HP / CG];
+#pragma unroll
+    for (int k = 0; k < HP / CG; ++k) {
+        const int c = cg + k * CG;
+        v[k] = (c < h && ok) ? xp[(size_t)c * D1 * pitch] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < HP / CG; ++k) {
+        const int c = cg + k * CG;
+        float g = 0.f;
+        if (c < h && ok) {
+            g = gelu_exact((v[k] - s.x) * s.y * w[c] + bvec[c]);
+            xp[(size_t)c * D1 * pitch] = g;
+        } else if (c == h && ok) {
+            g = 1.f;
+        }
+        Gs[c][col] = g;
+    }
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+    double *gout = gram + ((size_t)row * slots + blockIdx.x % slots) * HP * HP;
+    int t = 0;
+    for (int ti = 0; ti < NT; ++ti)
+        for (int tj = ti; tj < NT; ++tj, ++t) {
+            if (t % 4 != wave) continue;
+            if (ti * 32 > h) continue;                           // block rows above the ones row are zero
+            gram_f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            const float *ga = &Gs[ti * 32 + li][lh], *gb = &Gs[tj * 32 + li][lh];
+#pragma unroll 8
+            for (int k = 0; k < CT; k += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[k], gb[k], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, j = tj * 32 + li;
+                if (i <= h && j <= h) atomicAdd(gout + (size_t)i * HP + j, (double)acc[r]);
+            }
+        }
+}
+
+// statistics of z from the Gram accumulators of gn_gelu_gram_kernel (re-zeroed here: self-cleaning like the statistic slots).
+// wt: HP x HP float64 weights of the accumulated entries (host: W^T W on the diagonal blocks, doubled above them, 2 W^T b in
+// column h); ct: HP weights of column h for sum z (colsum W).  One workgroup per statistics row.
+__global__ __launch_bounds__(256) void gram_finalize_kernel(double *__restrict__ gram, int HP, int slots, int h, const double *__restrict__ wt,
+                                                            const double *__restrict__ ct, double sum_b, double sum_bsq, double cols,
+                                                            double count, float eps, float2 *__restrict__ out) {
+    __shared__ double red[2][4];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    double s1 = 0.0, s2 = 0.0;
+    for (int e = tid; e < HP * HP; e += 256) {
+        const int i = e / HP, j = e % HP;
+        if (i > h || j > h || (j >> 5) < (i >> 5)) continue;     // never written
+        double *p = gram + (size_t)row * slots * HP * HP + e;
+        double v[8];                                             // all loads before the stores that re-zero the slots
+#pragma unroll
+        for (int sl = 0; sl < 8; ++sl) v[sl] = sl < slots ? p[(size_t)sl * HP * HP] : 0.0;
+#pragma unroll
+        for (int sl = 0; sl < 8; ++sl)
+            if (sl < slots) p[(size_t)sl * HP * HP] = 0.0;
+        const double acc = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        s2 += wt[e] * acc;
+        if (j == h) s1 += ct[i] * acc;
+    }
+    for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_down(s1, off); s2 += __shfl_down(s2, off); }
+    if ((tid & 63) == 0) { red[0][tid >> 6] = s1; red[1][tid >> 6] = s2; }
+    __syncthreads();
+    if (tid == 0) {
+        s1 = red[0][0] + red[0][1] + red[0][2] + red[0][3] + cols * sum_b;
+        s2 = red[1][0] + red[1][1] + red[1][2] + red[1][3] + cols * sum_bsq;
+        const double mean = s1 / count;
+        double m2 = s2 - s1 * mean;
+        if (m2 < 0.0) m2 = 0.0;
+        out[row] = make_float2((float)mean, 1.0f / sqrtf((float)(m2 / count) + eps));
+    }
+}
+
+int gram_hp(int h) { return (h + 1 + 31) / 32 * 32; }
+
+int launch_gn_gelu_gram(float *x, int B, int h, int Cs, int D1, int D2, int pitch, int row_mode, const float2 *stats, const float *w,
+                        const float *b, double *gram, int slots, hipStream_t st) {
+    const int HP = gram_hp(h), rows = row_mode ? B * D1 : B, cols = row_mode ? D2 : D1 * D2;
+    MI_REQUIRE(HP <= 128, "gn_gelu_gram: %d hidden channels not instantiated", h);
+    MI_REQUIRE(row_mode || D1 == 1 || pitch == D2, "gn_gelu_gram: a per-item row needs contiguous positions");
+    const dim3 grid(ceil_div(cols, HP > 96 ? 64 : 128), rows);
+    if (HP == 32) hipLaunchKernelGGL(gn_gelu_gram_kernel<32>, grid, dim3(256), 0, st, x, h, Cs, D1, D2, pitch, row_mode, stats, w, b, gram, slots);
+    else if (HP == 64) hipLaunchKernelGGL(gn_gelu_gram_kernel<64>, grid, dim3(256), 0, st, x, h, Cs, D1, D2, pitch, row_mode, stats, w, b, gram, slots);
+    else if (HP == 96) hipLaunchKernelGGL(gn_gelu_gram_kernel<96>, grid, dim3(256), 0, st, x, h, Cs, D1, D2, pitch, row_mode, stats, w, b, gram, slots);
+    else hipLaunchKernelGGL(gn_gelu_gram_kernel<128>, grid, dim3(256), 0, st, x, h, Cs, D1, D2, pitch, row_mode, stats, w, b, gram, slots);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+
+int launch_gram_finalize(double *gram, int rows, int h, int slots, const double *wt, const double *ct, double sum_b, double sum_bsq,
+                         double cols, double count, float eps, float2 *out, hipStream_t st) {
+    MI_REQUIRE(slots >= 1 && slots <= 8, "gram_finalize: %d accumulator slots (1..8)", slots);
+    hipLaunchKernelGGL(gram_finalize_kernel, dim3(rows), dim3(256), 0, st, gram, gram_hp(h), slots, h, wt, ct, sum_b, sum_bsq, cols, count, eps, out);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+
 int launch_row_stats(const float *x, int rows, int64_t count, int64_t row_stride, double *stats, hipStream_t st) {
     const int nblk = (int)std::min<int64_t>(256, (count + 4095) / 4096);
     hipLaunchKernelGGL(row_stats_kernel, dim3(nblk, rows), dim3(256), 0, st, x, count, row_stride, stats);

@@ -191,6 +191,20 @@ int mi_attention(const float *q_dev, const float *k_dev, const float *v_dev, flo
 int mi_gn_gelu(float *x_dev, int32_t B, int32_t C, int32_t C_alloc, int32_t D1, int32_t D2, int32_t row_mode, const float *stats_dev,
                const float *w_dev, const float *b_dev, void *stream);
 
+/* The same GroupNorm(1, h) + GELU in place on the valid columns of x (B, C_alloc, D1, pitch >= D2) AND, in the same pass, the
+ *   Gram sums of the normalised hidden activations g per statistics row: gram_dev (rows x slots x HP x HP float64, zero on
+ *   entry, HP = mi_gram_order(h)) receives G[i][j] += g_i g_j for i, j <= h in the upper 32 x 32 block triangle, with
+ *   g_h = 1 (so G[i][h] = sum g_i).  They give the statistics of the GroupNorm(1, 2C) that follows DConv's 1x1 conv
+ *   z = W g + b (demucs/demucs.py:141-142) without evaluating it: mi_gram_finalize computes per row
+ *   sum z^2 = <wt, G> + cols * sum_bsq and sum z = ct . G[:, h] + cols * sum_b, writes (mean, rstd) float2 and re-zeroes
+ *   gram_dev.  wt_dev: HP x HP float64 (W^T W on diagonal blocks, 2 W^T W above them, 2 W^T b in column h); ct_dev: HP
+ *   float64 column sums of W. */
+int32_t mi_gram_order(int32_t h);
+int mi_gn_gelu_gram(float *x_dev, int32_t B, int32_t h, int32_t C_alloc, int32_t D1, int32_t D2, int32_t pitch, int32_t row_mode,
+                    const float *stats_dev, const float *w_dev, const float *b_dev, double *gram_dev, int32_t slots, void *stream);
+int mi_gram_finalize(double *gram_dev, int32_t rows, int32_t h, int32_t slots, const double *wt_dev, const double *ct_dev, double sum_b,
+                     double sum_bsq, double cols, double count, float eps, float *stats_out_dev, void *stream);
+
 /* LayerNorm over the channel axis of channel-first tokens x (B, C, T), optional additive table
  *   add_dev (C, T) (nn.LayerNorm at demucs/transformer.py:434-436,591-592 + positional
  *   embedding add :655-663). */

@@ -284,6 +284,57 @@ def test_gelu_erf_form_accuracy(lib):
     assert rel <= 1.0
 
 
+@pytest.mark.parametrize("case", ["freq_h24", "time_h48", "freq_h96"])
+def test_gn_gelu_gram_gives_second_groupnorm_statistics(lib, case):
+    """DConv's implicit-GEMM route (csrc/model.hip run_dconv): GroupNorm(1) + GELU of the hidden tensor in place and, from the
+    Gram sums of the same pass, the statistics of GroupNorm(1, 2C) after the 1x1 conv z = W g + b (demucs/demucs.py:139-142),
+    against a float64 evaluation of z.  Pitch-padded rows, ragged column tiles, both row modes, several accumulator slots."""
+    B, h, hp, D1, D2, pitch, row_mode, slots, C2 = {"freq_h24": (2, 24, 32, 3, 200, 208, 1, 1, 384),
+                                                     "time_h48": (2, 48, 48, 1, 1000, 1000, 0, 8, 768),
+                                                     "freq_h96": (1, 96, 96, 2, 150, 152, 1, 1, 768)}[case]
+    rows = B * D1 if row_mode else B
+    x = rnd(B, hp, D1, pitch, seed=70, scale=1.5).float()
+    st1 = torch.stack([rnd(rows, seed=71, scale=0.2), rnd(rows, seed=72).abs() + 0.5], 1).float().contiguous()
+    w, bb = (rnd(h, seed=73) + 1.0).float(), rnd(h, seed=74, scale=0.3).float()
+    W, b1 = rnd(C2, h, seed=75, scale=0.4).float().double(), rnd(C2, seed=76, scale=0.3).float().double()
+    # float64 reference
+    xs = x[:, :h, :, :D2].double()
+    srow = st1.double().view(B, D1, 2) if row_mode else st1.double().view(B, 1, 2).expand(B, D1, 2)
+    g = F.gelu((xs - srow[:, None, :, 0:1]) * srow[:, None, :, 1:2] * w.double()[None, :, None, None] + bb.double()[None, :, None, None])
+    z = torch.einsum("mh,bhdt->bmdt", W, g) + b1[None, :, None, None]
+    zr = z.permute(0, 2, 1, 3).reshape(rows, -1) if row_mode else z.reshape(B, -1)
+    mean, var = zr.mean(1), zr.var(1, unbiased=False)
+    # weights of the accumulators as csrc/model.hip load_dconv builds them
+    HP = lib.mi_gram_order(h)
+    A = W.t() @ W
+    wt = torch.zeros(HP, HP, dtype=torch.float64)
+    for i in range(h):
+        for k in range(h):
+            if k // 32 >= i // 32:
+                wt[i, k] = A[i, k] * (2.0 if k // 32 > i // 32 else 1.0)
+    wt[:h, h] = 2.0 * (W.t() @ b1)
+    ct = torch.zeros(HP, dtype=torch.float64)
+    ct[:h] = W.sum(0)
+    cols = D2 if row_mode else D1 * D2
+    xd, std, wd, bd = x.clone().cuda(), st1.cuda(), w.cuda(), bb.cuda()
+    gram = torch.zeros(rows * slots * HP * HP, dtype=torch.float64, device="cuda")
+    out = torch.empty(rows, 2, device="cuda")
+    _lib.check(lib.mi_gn_gelu_gram(xd.data_ptr(), B, h, hp, D1, D2, pitch, row_mode, std.data_ptr(), wd.data_ptr(), bd.data_ptr(),
+                                   gram.data_ptr(), slots, stream()), "mi_gn_gelu_gram")
+    wtd, ctd = wt.cuda(), ct.cuda()
+    _lib.check(lib.mi_gram_finalize(gram.data_ptr(), rows, h, slots, wtd.data_ptr(), ctd.data_ptr(), float(b1.sum()), float((b1 * b1).sum()),
+                                    float(cols), float(cols * C2), 1e-5, out.data_ptr(), stream()), "mi_gram_finalize")
+    torch.cuda.synchronize()
+    assert torch.allclose(xd[:, :h, :, :D2].cpu().double(), g, rtol=3e-6, atol=3e-6)           # normalised + GELU in place
+    assert torch.equal(xd[:, :, :, D2:].cpu(), x[:, :, :, D2:]) and torch.equal(xd[:, h:].cpu(), x[:, h:])      # pads untouched
+    got = out.cpu().double()
+    want_rstd = 1.0 / torch.sqrt(var + 1e-5)
+    e_mean, e_rstd = (got[:, 0] - mean).abs().max().item(), ((got[:, 1] - want_rstd).abs() / want_rstd).max().item()
+    print(f"{case}: mean err {e_mean:.2e}, rstd rel err {e_rstd:.2e}")
+    assert e_mean < 2e-6 * max(1.0, float(mean.abs().max())) and e_rstd < 2e-6
+    assert float(gram.abs().max()) == 0.0                                    # accumulators re-zeroed
+
+
 @pytest.mark.parametrize("dtype", [0, 1, 2], ids=["f32", "bf16", "f16"])
 def test_attention_matches_softmax(lib, dtype):
     """softmax(QK^T/8)V per head on channel-first q/k/v, ragged Tq (not a multiple of 128), cross
