@@ -1,0 +1,64 @@
+"""Seeded random `apply_model` configurations on a real MI355X against the pinned CPU oracle (oracle/apply_oracle.py on
+oracle/htdemucs_oracle.py, float32 with the reference's primitives): lengths from a third of a segment to 2.7 segments,
+overlaps, transition powers, shift counts, batches of tracks, segment overrides and a weighted bag -- the corners between the
+fixed reference goldens of tests/test_gpu_apply.py.  Both sides consume Python's `random` from the same seed, as the
+reference does (apply.py:245, transformer.py:680).  Tolerance: north_star's 1e-4 max-abs."""
+import random
+from fractions import Fraction
+
+import pytest
+import torch
+
+from demucs_amd import apply as P
+from demucs_amd.htdemucs import HTDemucs
+from demucs_amd.synth import synth_mix
+from demucs_amd.weights import HTDemucsConfig, synthetic_state_dict
+from oracle import apply_oracle as A
+from oracle import htdemucs_oracle as O
+
+pytestmark = pytest.mark.gpu
+SL = 343980
+TOL = 1e-4
+
+
+def draw_case(seed):
+    r = random.Random(1000 + seed)
+    length = int(SL * r.choice([0.31, 0.77, 1.0, 1.26, 1.9, 2.7]) + r.randrange(-3, 4))
+    case = dict(length=length, batch=r.choice([1, 1, 2]), shifts=r.choice([0, 0, 1, 2]), overlap=r.choice([0.1, 0.25, 0.5]),
+                transition_power=r.choice([1.0, 1.0, 2.0]), segment=r.choice([None, None, Fraction(39, 5), 6.0]),
+                bag=r.choice([False, False, True]), kind=r.choice(["tones", "noise"]), max_batch=r.choice([1, 3, 4]))
+    if case["shifts"] == 2 and length > 2 * SL:
+        case["shifts"] = 1                      # keeps the CPU oracle under a minute per case
+    return case
+
+
+@pytest.mark.parametrize("seed", [0, 2, 3, 4, 5])
+def test_random_configuration_matches_oracle(seed):
+    c = draw_case(seed)
+    cfg = HTDemucsConfig()
+    wseeds = [20 + seed, 40 + seed] if c["bag"] else [20 + seed]
+    sds = [synthetic_state_dict(cfg, s) for s in wseeds]
+    weights = [[1.0, 0.5, 0.0, 2.0], [0.25, 1.0, 1.0, 0.0]][:len(sds)]
+    engines = []
+    for sd in sds:
+        m = HTDemucs(cfg.sources, max_batch=c["max_batch"])
+        m.load_state_dict(sd)
+        engines.append(m)
+    oracles = [O.OracleModel(sd, cfg.sources) for sd in sds]
+    O.FAST_PRIMITIVES = True
+    try:
+        model = P.BagOfModels(engines, weights) if c["bag"] else engines[0]
+        omodel = A.Bag(oracles, weights) if c["bag"] else oracles[0]
+        mix = torch.stack([torch.from_numpy(synth_mix(300 + 7 * seed + b, c["length"], c["kind"])) for b in range(c["batch"])])
+        kw = dict(shifts=c["shifts"], overlap=c["overlap"], transition_power=c["transition_power"], segment=c["segment"])
+        random.seed(77 + seed)
+        got = P.apply_model(model, mix.cuda(), split=True, **kw).cpu()
+        state_after = random.getstate()
+        random.seed(77 + seed)
+        want = A.apply_model(omodel, mix, split=True, **kw)
+        assert random.getstate() == state_after, "the engine consumed Python's RNG differently from the reference algorithm"
+    finally:
+        O.FAST_PRIMITIVES = False
+    err = (got.double() - want.double()).abs().max().item()
+    print(f"seed {seed}: {c} -> max-abs {err:.2e} (out rms {want.pow(2).mean().sqrt():.3f})")
+    assert got.shape == want.shape == (c["batch"], 4, 2, c["length"]) and err <= TOL
