@@ -268,7 +268,7 @@ def main():
             del mix3
             # BASELINE configs[4], second model: the hdemucs_mmi architecture (Hybrid Demucs v3: BLSTM + LocalState, 44 s
             # segments as remote/hdemucs_mmi.yaml sets) in the fp16 mode on a 3-minute track: the five full chunks in one batched
-            # forward, the 15 s tail chunk in a second one
+            # forward, the 15 s tail chunk on the side engine under it
             from demucs_amd.hdemucs import HDemucs
             from demucs_amd.hdemucs_weights import HDemucsConfig, synthetic_hdemucs_state_dict
             hcfg = HDemucsConfig()
@@ -287,7 +287,7 @@ def main():
             result["modes"]["hdemucs_mmi fp16"] = {"dtype": "f16", "sources": 4, "value": round(TRACK_SECONDS / dt_s, 2), "unit": "audio-sec/wall-sec",
                                                    "ms_per_step": round(dt_s * 1e3, 2), "steps": 1,
                                                    "device_bytes": hm.device_bytes(),
-                                                   "note": "6 chunks (overlap 0.25): five of 44 s in one batched forward, the 15 s tail in another"}
+                                                   "note": "6 chunks (overlap 0.25): five of 44 s in one batched forward, the 15 s tail on the side engine and a side stream under it"}
             del o, hmix
             hm.release()
         if world == 1 and not args.no_cpu_baseline:

@@ -23,6 +23,7 @@ bookkeeping around `model(padded)`), which is also what the CPU host-logic tests
 from __future__ import annotations
 
 import ctypes as C
+import os
 import random
 from concurrent.futures import CancelledError, ThreadPoolExecutor
 from threading import Lock
@@ -32,7 +33,7 @@ import torch
 from torch.nn import functional as F
 
 from . import _lib
-from .hdemucs import HDemucs
+from .hdemucs import HDemucs, MIN_LENGTH as _HDEMUCS_MIN_LENGTH
 from .htdemucs import HTDemucs
 
 __all__ = ["apply_model", "BagOfModels", "TensorChunk", "tensor_chunk", "center_trim", "DummyPoolExecutor"]
@@ -343,6 +344,10 @@ def _apply_leaf(model, mix, common, callback, callback_arg) -> torch.Tensor:
 # ------------------------------------------------------------------------------------------------
 # device-resident split branch for the HIP engine
 # ------------------------------------------------------------------------------------------------
+def hdemucs_min_length() -> int:
+    return _HDEMUCS_MIN_LENGTH
+
+
 def _i64(values, device) -> torch.Tensor:
     return torch.tensor(list(values), dtype=torch.int64, device=device)
 
@@ -451,18 +456,46 @@ def ragged_split_accumulate(model: HDemucs, base: torch.Tensor, chunk_offset: in
     lens = [min(length - o, segment_length) for o in offsets]
     if weight.numel() < max(lens):
         raise ValueError(f"the weight ramp ({weight.numel()}) is shorter than a chunk ({max(lens)})")
+
+    def gather(offs, n):
+        seg = torch.empty(len(offs), channels, n, device=dev, dtype=torch.float32)
+        t_starts = _i64([chunk_offset + o for o in offs], dev)
+        _lib.check(lib.mi_segments_gather(base.data_ptr(), total, channels, t_starts.data_ptr(), len(offs), n, seg.data_ptr(),
+                                          seg.numel(), stream()), "mi_segments_gather")
+        return seg, t_starts
+
+    def overlap_add(out, offs, n):
+        nb = len(offs)
+        t_offs, t_lens, t_trims = _i64(offs, dev), _i32([n] * nb, dev), _i32([0] * nb, dev)
+        _lib.check(lib.mi_ola_accumulate(acc.data_ptr(), acc.shape[1], rows, out.data_ptr(), n, out.numel(),
+                                         t_offs.data_ptr(), t_lens.data_ptr(), t_trims.data_ptr(), nb, offs[0],
+                                         min(acc.shape[1], offs[-1] + n), weight.data_ptr(), weight.numel(), stream()),
+                   "mi_ola_accumulate")
+        return t_offs, t_lens, t_trims
+
     with torch.cuda.device(dev):
+        # A track's tail chunk is shorter than the others, so it cannot join their batch, and a forward of this architecture
+        # costs 1 600 dependent LSTM step launches whatever its size: without listeners (whose events must fire in order) it
+        # runs on the model's single-item side engine and a side stream, under the batched forward of the full chunks; its
+        # overlap-add still comes last, as in the reference's loop.
+        side = None
+        n_main = len(offsets)
+        if (on_start is None and on_end is None and len(offsets) >= 2 and lens[-1] < lens[-2]
+                and lens[-1] >= hdemucs_min_length() and os.environ.get("MI_NO_TAIL_OVERLAP") is None):
+            main_stream, side = torch.cuda.current_stream(dev), model.side_stream()
+            side.wait_stream(main_stream)                 # `base` and whatever produced it
+            with torch.cuda.stream(side):
+                tail_seg, tail_idx = gather([offsets[-1]], lens[-1])
+                tail_out = model(tail_seg, aux=True)
+            n_main -= 1
         i = 0
-        while i < len(offsets):
+        while i < n_main:
             n, j = lens[i], i + 1
-            while j < len(offsets) and j - i < model.max_batch and lens[j] == n:
+            while j < n_main and j - i < model.max_batch and lens[j] == n:
                 j += 1
-            offs, nb = list(offsets[i:j]), j - i
+            offs = list(offsets[i:j])
             i = j
-            seg = torch.empty(nb, channels, n, device=dev, dtype=torch.float32)
-            t_starts = _i64([chunk_offset + o for o in offs], dev)
-            _lib.check(lib.mi_segments_gather(base.data_ptr(), total, channels, t_starts.data_ptr(), nb, n, seg.data_ptr(),
-                                              seg.numel(), stream()), "mi_segments_gather")
+            seg, t_starts = gather(offs, n)
             if on_start is not None:
                 on_start(offs[0])
             out = model(seg)
@@ -473,11 +506,12 @@ def ragged_split_accumulate(model: HDemucs, base: torch.Tensor, chunk_offset: in
                     on_start(o)
                 if on_end is not None:
                     on_end(o)
-            t_offs, t_lens, t_trims = _i64(offs, dev), _i32([n] * nb, dev), _i32([0] * nb, dev)
-            _lib.check(lib.mi_ola_accumulate(acc.data_ptr(), acc.shape[1], rows, out.data_ptr(), n, out.numel(),
-                                             t_offs.data_ptr(), t_lens.data_ptr(), t_trims.data_ptr(), nb, offs[0],
-                                             min(acc.shape[1], offs[-1] + n), weight.data_ptr(), weight.numel(), stream()),
-                       "mi_ola_accumulate")
+            keep = overlap_add(out, offs, n)                      # noqa: F841  (index tensors stay referenced until enqueued)
+        if side is not None:
+            main_stream.wait_stream(side)
+            for t in (tail_seg, tail_idx, tail_out):
+                t.record_stream(main_stream)                      # allocated under the side stream, consumed on this one
+            keep = overlap_add(tail_out, [offsets[-1]], lens[-1])  # noqa: F841
 
 
 def device_split_finish(acc: torch.Tensor, acc_origin: int, length: int, offsets: Sequence[int], segment_length: int,
@@ -529,8 +563,9 @@ def _apply_split_device(model, mix, common, callback, callback_arg) -> torch.Ten
         base = chunk.tensor[b].to(device=device, dtype=torch.float32).contiguous()       # whole track resident in HBM
         acc = out[b].view(S * channels, length) if on_device else torch.zeros(S * channels, length, device=device, dtype=torch.float32)
         if ragged:
+            listen = first and (callback is not None or bar is not None)     # no listener: the tail chunk may overlap the others
             ragged_split_accumulate(model, base, chunk.offset, length, offsets, segment_length, weight, acc,
-                                    on_start if first else None, on_end if first else None)
+                                    on_start if listen else None, on_end if listen else None)
         else:
             device_split_accumulate(model, base, chunk.offset, length, offsets, segment_length, valid_length, weight, acc, 0,
                                     on_start if first else None, on_end if first else None, draw_rng=first)

@@ -56,7 +56,8 @@ class HDemucs:
         self.compute_dtype = compute_dtype
         self._schema = hdemucs_schema(cfg)
         self._state: Optional["OrderedDict[str, np.ndarray]"] = None
-        self._handles: Dict[torch.device, tuple] = {}          # device -> (handle, max_length)
+        self._handles: Dict[tuple, tuple] = {}          # (device, aux) -> (handle, max_length); aux: the single-item side engine
+        self._side_streams: Dict[torch.device, "torch.cuda.Stream"] = {}
         self._device: Optional[torch.device] = None
         self.training = False
 
@@ -106,7 +107,7 @@ class HDemucs:
     # ---- engine handle ------------------------------------------------------------------------------------------
     def _release(self):
         handles, self._handles = self._handles, {}
-        for dev, (h, _) in handles.items():
+        for (dev, _aux), (h, _) in handles.items():
             with torch.cuda.device(dev):
                 _lib.load().mi_hmodel_destroy(C.c_void_p(h))
 
@@ -118,20 +119,21 @@ class HDemucs:
         except Exception:
             pass
 
-    def _ensure_handle(self, length: int) -> int:
+    def _ensure_handle(self, length: int, aux: bool = False) -> int:
         if self._state is None:
             raise RuntimeError("HDemucs has no weights: call load_state_dict first")
         if self._device is None or self._device.type != "cuda":
             raise _lib.EngineError("demucs_amd.HDemucs only runs on a GPU device (MI355X); call .to('cuda'). "
                                    "There is no CPU implementation in this package.")
-        have = self._handles.get(self._device)
+        key = (self._device, bool(aux))
+        have = self._handles.get(key)
         if have is not None and have[1] >= length:
             return have[0]
         lib = _lib.load()
         if have is not None:                            # a longer chunk than the workspace was sized for: re-create
             with torch.cuda.device(self._device):
                 lib.mi_hmodel_destroy(C.c_void_p(have[0]))
-            del self._handles[self._device]
+            del self._handles[key]
         max_length = max(int(length), int(float(self.segment) * self.samplerate), MIN_LENGTH)
         names = list(self._state)
         descs = (_lib.MiTensorDesc * len(names))()
@@ -140,21 +142,29 @@ class HDemucs:
             descs[i].name = k.encode()
             descs[i].data = v.ctypes.data
             descs[i].numel = v.size
-        cfg = _lib.MiConfig(len(self.sources), max_length, self.max_batch, self.COMPUTE_DTYPES[self.compute_dtype])
+        cfg = _lib.MiConfig(len(self.sources), max_length, 1 if aux else self.max_batch, self.COMPUTE_DTYPES[self.compute_dtype])
         h = C.c_void_p()
         with torch.cuda.device(self._device):
             _lib.check(lib.mi_hmodel_create(C.byref(cfg), descs, len(names), C.byref(h)), "mi_hmodel_create")
-        self._handles[self._device] = (h.value, max_length)
+        self._handles[key] = (h.value, max_length)
         return h.value
 
+    def side_stream(self) -> "torch.cuda.Stream":
+        """Stream on which `apply_model` runs a track's shorter tail chunk (on the single-item side engine: `forward(..., aux=True)`)
+        while the batched forward of the full chunks runs on the caller's stream."""
+        st = self._side_streams.get(self._device)
+        if st is None:
+            st = self._side_streams[self._device] = torch.cuda.Stream(self._device)
+        return st
+
     def device_bytes(self) -> int:
-        have = self._handles.get(self._device)
-        return int(_lib.load().mi_hmodel_device_bytes(C.c_void_p(have[0]))) if have else 0
+        lib = _lib.load()
+        return sum(int(lib.mi_hmodel_device_bytes(C.c_void_p(h))) for (dev, _aux), (h, _) in self._handles.items() if dev == self._device)
 
     def tap(self, name: str, batch: int) -> torch.Tensor:
         """Copy of an internal activation of the last forward (parity tests), shape (batch, numel)."""
         lib, n = _lib.load(), C.c_int64()
-        h = C.c_void_p(self._handles[self._device][0])
+        h = C.c_void_p(self._handles[(self._device, False)][0])
         _lib.check(lib.mi_hmodel_tap(h, name.encode(), None, batch, C.byref(n), None), "mi_hmodel_tap")
         out = torch.empty(batch, n.value, device=self._device, dtype=torch.float32)
         with torch.cuda.device(self._device):
@@ -163,8 +173,10 @@ class HDemucs:
         return out
 
     # ---- forward --------------------------------------------------------------------------------------------------
-    def __call__(self, mix: torch.Tensor) -> torch.Tensor:
-        """HDemucs.forward in eval mode (hdemucs.py:689-794): float32 (B, 2, n) -> (B, S, 2, n), any n >= 64."""
+    def __call__(self, mix: torch.Tensor, aux: bool = False) -> torch.Tensor:
+        """HDemucs.forward in eval mode (hdemucs.py:689-794): float32 (B, 2, n) -> (B, S, 2, n), any n >= 64.
+        aux=True runs on the single-item side engine (its own workspace), so that it may overlap a forward of the main one
+        on another stream; the results are the same bit for bit."""
         if mix.dim() != 3 or mix.shape[1] != self.audio_channels:
             raise ValueError(f"expected (B, {self.audio_channels}, n), got {tuple(mix.shape)}")
         if mix.dtype != torch.float32:
@@ -172,15 +184,16 @@ class HDemucs:
         B, _, length = mix.shape
         if length < MIN_LENGTH:
             raise ValueError(f"demucs_amd.HDemucs needs at least {MIN_LENGTH} samples per forward, got {length}")
-        handle = self._ensure_handle(length)
+        handle = self._ensure_handle(length, aux)
         if mix.device != self._device:
             raise _lib.EngineError(f"mix is on {mix.device} but the model is on {self._device}")
         mix = mix.contiguous()
         out = torch.empty(B, len(self.sources), self.audio_channels, length, device=mix.device, dtype=torch.float32)
         lib = _lib.load()
         with torch.cuda.device(self._device):
-            for b0 in range(0, B, self.max_batch):
-                nb = min(self.max_batch, B - b0)
+            step = 1 if aux else self.max_batch
+            for b0 in range(0, B, step):
+                nb = min(step, B - b0)
                 _lib.check(lib.mi_hmodel_forward(C.c_void_p(handle), mix[b0:b0 + nb].data_ptr(), out[b0:b0 + nb].data_ptr(), nb, length,
                                                  C.c_void_p(_lib.current_stream_ptr())), "mi_hmodel_forward")
         return out

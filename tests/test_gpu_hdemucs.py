@@ -170,3 +170,21 @@ def test_short_chunks_match_float64_oracle(length):
     err = (out.double() - want).abs().max().item()
     print(f"hdemucs {length} samples: max-abs {err:.3e} (out rms {want.pow(2).mean().sqrt():.3f})")
     assert out.shape == (1, 4, 2, length) and err <= TOL
+
+
+def test_tail_chunk_overlap_is_bit_identical_and_stable(monkeypatch):
+    """Without listeners `apply_model` runs a track's shorter tail chunk on the side engine and a side stream while the full
+    chunks' batched forward runs (demucs_amd/apply.py ragged_split_accumulate): the result must equal the sequential
+    schedule's bit for bit -- float32 and fp16 modes, 12 repeats each (two kernel streams share the CUs here)."""
+    L = int(2.4 * 4 * 44100) + 777                  # segment override 4 s: offsets 0, 3 s, 6 s, 9 s -> 3 full chunks + a 0.6 s tail
+    mix = torch.from_numpy(synth_mix(77, L, "noise"))[None].cuda()
+    for dtype in ("f32", "f16"):
+        m = engine(1, max_batch=3, compute_dtype=dtype)
+        monkeypatch.setenv("MI_NO_TAIL_OVERLAP", "1")
+        want = P.apply_model(m, mix, shifts=0, overlap=0.25, segment=4)
+        monkeypatch.delenv("MI_NO_TAIL_OVERLAP")
+        for rep in range(12):
+            got = P.apply_model(m, mix, shifts=0, overlap=0.25, segment=4)
+            assert torch.equal(got, want), f"{dtype} repeat {rep}: overlapped tail differs, max {float((got - want).abs().max()):.3e}"
+        assert (m._device, True) in m._handles           # the side engine really ran
+        m.release()
