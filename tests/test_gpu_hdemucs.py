@@ -90,7 +90,7 @@ def test_many_sequences_span_several_lstm_tiles():
     """A batch of 7 items of 23.3 s: the BLSTM of encoder.4 sees 7 x 11 = 77 framed sequences (sequence tiles of 32, 32
     and 13 in `lstm_step_kernel`), encoder.5's 7 x 6 = 42 (32 + 10), and LocalState runs over 1 004 / 502 positions with
     a ragged last key tile -- the geometry of the 44-second production chunks, checked sample by sample against the
-    float64 oracle (the 4-second cases above stay inside one tile)."""
+    float32 oracle (the 4-second cases above, against the float64 one, stay inside one tile)."""
     from demucs_amd.hdemucs_weights import hdemucs_layer_plan
     from oracle import hdemucs_oracle as HO
     cfg = HDemucsConfig()
@@ -101,9 +101,9 @@ def test_many_sequences_span_several_lstm_tiles():
     m.to("cuda")
     mix = torch.stack([torch.from_numpy(synth_mix(60 + b, L, "tones" if b % 2 else "noise")) for b in range(B)])
     out = m(mix.cuda()).cpu()
-    osd = {k: torch.from_numpy(v.copy()).double() for k, v in sd.items()}
+    osd = {k: torch.from_numpy(v.copy()) for k, v in sd.items()}          # float32 oracle (its own error ~1e-5): half the CPU time
     with torch.no_grad():
-        want = HO.hdemucs_forward(osd, mix.double(), hdemucs_layer_plan(cfg), 4)
+        want = HO.hdemucs_forward(osd, mix, hdemucs_layer_plan(cfg), 4).double()
     err = (out.double() - want).abs().amax(dim=(1, 2, 3))
     print(f"hdemucs 7 x 23.3 s: per-item max-abs {[f'{e:.2e}' for e in err.tolist()]} (out rms {want.pow(2).mean().sqrt():.3f})")
     assert float(err.max()) <= TOL
