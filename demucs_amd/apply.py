@@ -447,7 +447,8 @@ def ragged_split_accumulate(model: HDemucs, base: torch.Tensor, chunk_offset: in
     """`device_split_accumulate` for a model WITHOUT `valid_length` (HDemucs): the leaf forwards every chunk at its own
     length, unpadded (apply.py:309-310), so consecutive chunks of equal length -- all but the last of a track -- share one
     gather, one batched forward of up to `model.max_batch` chunks and one overlap-add; the shorter tail chunk gets its
-    own.  Events fire in the reference's order (start, end, start, end ...), as in `device_split_accumulate`."""
+    own, overlapped with the batched one on the model's side engine and stream when no listener needs ordered events.
+    Events fire in the reference's order (start, end, start, end ...), as in `device_split_accumulate`."""
     lib = _lib.load()
     dev = base.device
     channels, total = base.shape
