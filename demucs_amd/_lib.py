@@ -45,6 +45,7 @@ class MiConvDesc(C.Structure):
         ("stats", C.c_void_p), ("gn_stats", C.c_void_p), ("gn_w", C.c_void_p), ("gn_b", C.c_void_p),
         ("out_len", C.c_int32), ("tile_m", C.c_int32), ("plain", C.c_int32), ("half", C.c_int32),
         ("o2_valid", C.c_int32), ("ktab_len", C.c_int32), ("sink", C.c_void_p), ("wx", C.c_void_p), ("tr_stride", C.c_int32), ("tr_pad", C.c_int32), ("x_ld", C.c_int32), ("x_ld_pad", C.c_int32), ("wh", C.c_void_p),
+        ("xh", C.c_void_p), ("xh_n", C.c_int64), ("yh", C.c_void_p), ("yh_n", C.c_int64),
     ]
 
 

@@ -32,6 +32,7 @@ enum mi_epilogue {
  * per-column (mean, rstd) of the RAW input in `pro_stats` (float2 per output column):
  *     y = act( rstd[n] * (acc - mean[n] * c1[m]) + c2[m] )                                      */
 #define MI_FLAG_LN 32
+#define MI_FLAG_IMG 64     /* LINEAR, half modes: the result goes to `yh` as a 16-bit operand image instead of `y` */
 
 typedef struct mi_ktab_entry {
     int32_t off; /* element offset added to the column base: ci*chan_stride + d1*D2 + d2 */
@@ -83,6 +84,13 @@ typedef struct mi_conv_desc {
                                the hdemucs engine: D2 stays the VALID length the gather bounds test against)                   */
     int32_t x_ld_pad;
     const void *wh;         /* `half` != 0: the weights as Wh[ceil(Kpad/32)*4][Mpad][8] bf16 / fp16 (mi_conv_pack_half)           */
+    /* 16-bit operand images of GEMM-only activations (half modes, plain LINEAR layers): Img[rows / 8][n_img][8] with the
+       column index n = b * O1 * O2 + p of the tensor -- the order a K step's B tile has in LDS, so a consumer moves it
+       global -> LDS by DMA without conversion */
+    const void *xh;         /* NULL, or the INPUT as such an image (K % 8 == 0): x is then ignored                              */
+    int64_t xh_n;           /* its column count                                                                               */
+    void *yh;               /* MI_FLAG_IMG: the OUTPUT image (M % 8 == 0); y is not written                                      */
+    int64_t yh_n;
 } mi_conv_desc;
 
 #ifdef __cplusplus

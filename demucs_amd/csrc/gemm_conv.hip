@@ -386,6 +386,10 @@ int launch_conv(const mi_conv_desc &din, hipStream_t st) {
     const int64_t P = (int64_t)d.O1 * d.O2;
     const bool plain = d.plain && d.K == d.Kpad && P % 4 == 0 && d.x_bstride % 4 == 0 && ((uintptr_t)d.x & 15) == 0 &&
                        d.S1 == 1 && d.S2 == 1 && d.D1 == d.O1 && (d.x_ld ? d.x_ld : d.D2) == d.O2;
+    MI_REQUIRE(!(d.flags & MI_FLAG_IMG) || (d.half && d.yh && d.epi == MI_EPI_LINEAR && d.M % 8 == 0 && d.yh_n >= (int64_t)d.B * P &&
+                                            ((uintptr_t)d.yh & 15) == 0),
+               "conv: MI_FLAG_IMG needs a half-precision LINEAR layer with M %% 8 == 0 and an aligned output image of >= B * P columns");
+    MI_REQUIRE(!d.xh || d.half, "conv: an operand-image input needs a half-precision layer");
     if (d.half) return launch_conv_half(d, tile, plain, st);
     static const int x6_mode = getenv("MI_X6_MODE") ? atoi(getenv("MI_X6_MODE")) : 0;   // bisecting: 1 plain only, 2 gather only
     static const int x6_class = getenv("MI_X6_CLASS") ? atoi(getenv("MI_X6_CLASS")) : -1;   // bisecting: one kernel class only

@@ -240,6 +240,115 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_half_kernel(const mi_conv_de
     conv_epilogue<TM, TN, EPI, LFLAGS>(d, acc, m0, n0, wm, wn, N, P, o2v);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Plain LINEAR layer whose INPUT exists as a 16-bit operand image (mi_conv_desc.xh: the FFN hidden tensor, written in that
+// form by lin1's epilogue): both operand tiles are already in LDS order, so they go global -> LDS with
+// global_load_lds_dwordx4 through a 3-stage ring -- TWO K steps in flight behind a counted s_waitcnt vmcnt, one raw
+// s_barrier per K step, no staging registers, no conversion (the scheme of conv_gemm_dma_kernel in gemm_conv.hip).
+// BM = 64 TM rows; a stage is 4 BM + 512 sixteen-byte words (24 KiB at TM = 4: two workgroups per CU).
+typedef __attribute__((address_space(1))) const void hgvoid_t;
+typedef __attribute__((address_space(3))) void hlvoid_t;
+
+template <int HT, int TM, int LFLAGS>
+__global__ __launch_bounds__(256, 2) void conv_gemm_half_img_kernel(const mi_conv_desc d, const int N, const int MT, const int Gm) {
+    constexpr int TN = 2, WN = 2, BM = 2 * TM * 32, NA = BM / 64;
+    constexpr int A_W = 4 * BM, SW = A_W + 4 * BN;                  // 16-byte words per stage: A image then B image
+    __shared__ __attribute__((aligned(16))) uint4 smem[3 * SW];
+    {
+        float agpr_anchor = 0.f;
+        asm volatile("; accumulators in AGPRs %0" : "+a"(agpr_anchor));
+    }
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    int mt, nt;
+    if (!tile_of_block(MT, Gm, N, mt, nt)) return;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int P = d.O1 * d.O2;
+    const int o2v = d.o2_valid ? d.o2_valid : d.O2;
+    const int nk = (d.Kpad + HK - 1) / HK;
+
+    // A: flat [octet][row] image of the K step; wave instruction i = wave * NA + j covers words 64 i .. 64 i + 63
+    const uint4 *wh = reinterpret_cast<const uint4 *>(d.wh);
+    const uint4 *asrc[NA];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+        const int w = 64 * (wave * NA + j) + lane;
+        asrc[j] = wh + (size_t)(w / BM) * d.Mpad + m0 + w % BM;
+    }
+    const size_t a_step = (size_t)4 * d.Mpad;
+    // B: this wave moves octet `wave` of the K step, columns [0, 64) and [64, 128) of the tile; columns outside the tensor
+    // and octets past K come from the zero page
+    const uint4 *xh = reinterpret_cast<const uint4 *>(d.xh);
+    const uint4 *zero = reinterpret_cast<const uint4 *>(d.sink + 256);
+    const bool c0 = n0 + lane < N, c1 = n0 + 64 + lane < N;
+    const uint4 *b0 = xh + (size_t)wave * d.xh_n + n0 + lane;
+    const size_t b_step = (size_t)4 * d.xh_n;
+
+#define MI_IMG_TILE(kt, stage)                                                                                      \
+    do {                                                                                                            \
+        uint4 *sa = smem + (stage) * SW + 64 * (wave * NA), *sb = smem + (stage) * SW + A_W + wave * BN;             \
+        _Pragma("unroll") for (int j = 0; j < NA; ++j)                                                               \
+            __builtin_amdgcn_global_load_lds((hgvoid_t *)(asrc[j] + (size_t)(kt) * a_step), (hlvoid_t *)(sa + 64 * j), 16, 0, 0); \
+        const bool kin = ((kt) * 4 + wave) * 8 < d.K;                                                               \
+        const uint4 *g = b0 + (size_t)(kt) * b_step;                                                                \
+        __builtin_amdgcn_global_load_lds((hgvoid_t *)((kin && c0) ? g : zero), (hlvoid_t *)sb, 16, 0, 0);            \
+        __builtin_amdgcn_global_load_lds((hgvoid_t *)((kin && c1) ? g + 64 : zero), (hlvoid_t *)(sb + 64), 16, 0, 0); \
+    } while (0)
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int li = lane & 31, lh = lane >> 5;
+    MI_IMG_TILE(0, 0);
+    if (nk > 1) MI_IMG_TILE(1, 1);
+    int stage = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        // tile kt has landed once all but this wave's newest tile (NA + 2 instructions) are done -- for every wave
+        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + 2) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        // stage (kt + 2) % 3 was last read in the previous iteration, which every wave has finished
+        if (kt + 2 < nk) MI_IMG_TILE(kt + 2, stage == 0 ? 2 : stage - 1);
+        const uint4 *As = smem + stage * SW, *Bs = As + A_W;
+        uint4 af[2][TM], bf[2][TN];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+#pragma unroll
+            for (int a = 0; a < TM; ++a) af[s][a] = As[(2 * s + lh) * BM + (wm * TM + a) * 32 + li];
+#pragma unroll
+            for (int b = 0; b < TN; ++b) bf[s][b] = Bs[(2 * s + lh) * BN + (wn * TN + b) * 32 + li];
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b) acc[a][b] = mfma16<HT>(af[s][a], bf[s][b], acc[a][b]);
+        stage = stage == 2 ? 0 : stage + 1;
+    }
+#undef MI_IMG_TILE
+    conv_epilogue<TM, TN, MI_EPI_LINEAR, LFLAGS>(d, acc, m0, n0, wm, wn, N, P, o2v);
+}
+
+template <int HT, int TM, int LFLAGS>
+static int launch_half_img(const mi_conv_desc &d, hipStream_t st) {
+    constexpr int BM = 2 * TM * 32;
+    const int64_t N64 = (int64_t)d.B * d.O1 * d.O2;
+    MI_REQUIRE(N64 < (1ll << 31) - 256 && N64 <= d.xh_n, "conv: %lld output positions, operand image has %lld columns", (long long)N64,
+               (long long)d.xh_n);
+    MI_REQUIRE(d.Mpad % BM == 0 && d.K % 8 == 0 && ((uintptr_t)d.xh & 15) == 0, "conv: operand-image layer needs Mpad %% %d == 0, K %% 8 == 0", BM);
+    const int N = (int)N64, MT = d.Mpad / BM, NT = ceil_div(N, BN);
+    hipLaunchKernelGGL((conv_gemm_half_img_kernel<HT, TM, LFLAGS>), dim3(grouped_grid(MT, NT, 1)), dim3(256), 0, st, d, N, MT, 1);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+
 template <int HT, int WM, int WN, int TM, int TN, int EPI, int LFLAGS, bool PLAIN>
 static int launch_cfg_half(const mi_conv_desc &d, hipStream_t st) {
     constexpr int BM = WM * TM * 32;
@@ -276,8 +385,14 @@ static int launch_conv_half_t(const mi_conv_desc &d, int tile, bool plain, hipSt
     case E: return plain ? launch_tile_half<HT, E, 0, true>(d, tile, st) : launch_tile_half<HT, E, 0, false>(d, tile, st)
 #define MI_LINEAR(F)                                                \
     case F: return plain ? launch_tile_half<HT, MI_EPI_LINEAR, F, true>(d, tile, st) : launch_tile_half<HT, MI_EPI_LINEAR, F, false>(d, tile, st)
+    if (d.xh) {         // input given as a 16-bit operand image: the FFN's second linear layer
+        MI_REQUIRE(d.epi == MI_EPI_LINEAR && plain && (d.flags & (MI_FLAG_GELU | MI_FLAG_SCALE | MI_FLAG_RES | MI_FLAG_LN | MI_FLAG_IMG)) ==
+                   (MI_FLAG_SCALE | MI_FLAG_RES), "conv: an operand-image input is instantiated for plain LINEAR scale+residual layers");
+        return d.Mpad % 256 == 0 ? launch_half_img<HT, 4, MI_FLAG_SCALE | MI_FLAG_RES>(d, st) : launch_half_img<HT, 2, MI_FLAG_SCALE | MI_FLAG_RES>(d, st);
+    }
     if (d.epi == MI_EPI_LINEAR) {
-        switch (d.flags & (MI_FLAG_GELU | MI_FLAG_SCALE | MI_FLAG_RES | MI_FLAG_LN)) {
+        switch (d.flags & (MI_FLAG_GELU | MI_FLAG_SCALE | MI_FLAG_RES | MI_FLAG_LN | MI_FLAG_IMG)) {
+            MI_LINEAR(MI_FLAG_LN | MI_FLAG_GELU | MI_FLAG_IMG);
             MI_LINEAR(0);
             MI_LINEAR(MI_FLAG_GELU);
             MI_LINEAR(MI_FLAG_RES);

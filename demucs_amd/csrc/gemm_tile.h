@@ -48,6 +48,18 @@ __device__ __forceinline__ float gather_b(const mi_conv_desc &d, const mi_ktab_e
     return *p;
 }
 
+// two floats -> two bf16 / fp16 values (round to nearest even) in one dword, `a` in the low half
+__device__ __forceinline__ unsigned pack_half2(int dtype, float a, float b) {
+    typedef __bf16 pk_bf16x2 __attribute__((ext_vector_type(2)));
+    typedef _Float16 pk_f16x2 __attribute__((ext_vector_type(2)));
+    if (dtype == 1 /* MI_DTYPE_BF16 */) {
+        const pk_bf16x2 h = {(__bf16)a, (__bf16)b};
+        return __builtin_bit_cast(unsigned, h);
+    }
+    const pk_f16x2 h = {(_Float16)a, (_Float16)b};
+    return __builtin_bit_cast(unsigned, h);
+}
+
 // PLAIN = 1x1 / linear layer with K % 16 == 0 and (O1*O2) % 4 == 0: no gather table, float4 activation loads.
 // Epilogue shared by the register-staged and the LDS-DMA main loops.
 // acc[a][b][r] is C[m][n] with n = n0 + (wn*TN + b)*32 + li, m = m0 + (wm*TM + a)*32 + (r & 3) + 8 * (r >> 2) + 4 * lh
@@ -88,7 +100,7 @@ __device__ __forceinline__ void conv_epilogue(const mi_conv_desc &d, f32x16 (&ac
                 const size_t colbase = c.valid ? (size_t)c.b * d.y_bstride + c.p : 0;
                 float *const ycol = d.y + colbase;
                 const int cs = (int)d.y_cstride;
-                float resv[16];
+                float resv[16], vq[4];
                 if (LFLAGS & MI_FLAG_RES) {
                     const float *const rcol = d.res + colbase;
 #pragma unroll
@@ -106,6 +118,16 @@ __device__ __forceinline__ void conv_epilogue(const mi_conv_desc &d, f32x16 (&ac
                     if (LFLAGS & MI_FLAG_GELU) v = gelu_exact(v);
                     if (LFLAGS & MI_FLAG_SCALE) v *= auxr[r];
                     if (LFLAGS & MI_FLAG_RES) v += resv[r];
+                    if (LFLAGS & MI_FLAG_IMG) {
+                        // four consecutive rows of a k-octet of the NEXT layer's operand: one 8-byte store into its image
+                        vq[r & 3] = v;
+                        if ((r & 3) == 3) {
+                            const int mo = mbase + 8 * (r >> 2);               // = 8 * octet + 4 * lh
+                            uint2 *dst = reinterpret_cast<uint2 *>(d.yh) + ((size_t)(mo >> 3) * d.yh_n + n) * 2 + lh;
+                            if (c.valid && mo < d.M) *dst = make_uint2(pack_half2(d.half, vq[0], vq[1]), pack_half2(d.half, vq[2], vq[3]));
+                        }
+                        continue;
+                    }
                     // branch-free: out-of-range rows / columns are stored to a per-lane sink word
                     *((c.valid && m < d.M) ? ycol + m * cs : sink) = v;
                 }

@@ -721,8 +721,14 @@ int Model::run_tr_layer(int br, int k, int B, const float *x, const float2 *xsta
         d.plain = 1; d.epi = MI_EPI_LINEAR; d.flags = MI_FLAG_LN | MI_FLAG_GELU; d.scale = l.lin1_c1;
         d.pro_stats = (const float *)w_tr_stat1[br];
         d.y = ffh; d.y_bstride = (int64_t)2048 * Tq; d.y_cstride = Tq;
+        // half modes: the hidden tensor only ever feeds lin2's matrix product, so lin1 writes it as lin2's 16-bit operand
+        // image (into the same buffer) and lin2 moves both operands global -> LDS by DMA (gemm_half.hip)
+        static const bool no_img = getenv("MI_NO_FFN_IMAGE") != nullptr;
+        const bool img = d.half != 0 && !no_img;
+        if (img) { d.flags |= MI_FLAG_IMG; d.yh = ffh; d.yh_n = (int64_t)B * Tq; }
         MI_TRY(conv(d, st));
         mi_conv_desc e = base_desc(l.lin2, tr_ktab2048[br], ffh, (int64_t)2048 * Tq, gq);
+        if (img) { e.xh = ffh; e.xh_n = (int64_t)B * Tq; }
         e.plain = 1; e.epi = MI_EPI_LINEAR; e.flags = MI_FLAG_SCALE | MI_FLAG_RES; e.scale = l.gamma2; e.res = x1;
         e.y = x2; e.y_bstride = (int64_t)512 * Tq; e.y_cstride = Tq;
         MI_TRY(conv(e, st));

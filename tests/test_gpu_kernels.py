@@ -335,6 +335,41 @@ def test_gn_gelu_gram_gives_second_groupnorm_statistics(lib, case):
     assert float(gram.abs().max()) == 0.0                                    # accumulators re-zeroed
 
 
+@pytest.mark.parametrize("mode", ["bf16", "f16"])
+def test_ffn_operand_image_round_trip(lib, mode):
+    """Half modes, transformer FFN (transformer.py:339-343 linear1 -> GELU -> linear2): lin1's epilogue writes the hidden
+    tensor as lin2's 16-bit operand image (MI_FLAG_IMG) and lin2 consumes it by DMA (mi_conv_desc.xh).  The image must hold
+    exactly the rounding of the float32 result the plain epilogue stores, laid out [rows / 8][columns][8]; lin2 on the image
+    must equal lin2 on the float32 tensor (same operands after rounding).  Ragged column count, 128- and 256-row tiles."""
+    B, P, Kin, H = 2, 168, 64, 256                       # N = 336: two full column tiles and a ragged one
+    N = B * P
+    x = rnd(B, Kin, P, seed=80).float().cuda()
+    W1, b1 = rnd(H, Kin, seed=81, scale=0.3), rnd(H, seed=82, scale=0.2)
+    wt1, bias1, M1, Mpad1, K1, Kpad1, _ = pack_w(W1, b1, tile=128)
+    ident = torch.stack([torch.zeros(N), torch.ones(N)], 1).float().cuda().contiguous()      # LayerNorm fold with mean 0, rstd 1
+    c1 = torch.zeros(Mpad1, device="cuda")
+    common1 = dict(wt=wt1, M=M1, Mpad=Mpad1, K=K1, Kpad=Kpad1, ktab=ktab(Kin, 1, 1, 1, 1, 0, 0, P, P, Kpad1), x=x, x_bstride=Kin * P,
+                   B=B, D1=1, D2=P, O1=1, O2=P, S1=1, S2=1, bias=bias1, epi=EPI_LINEAR, scale=c1, pro_stats=ident, tile_m=128, plain=1, x6=mode)
+    hid = torch.empty(B, H, P, device="cuda")
+    conv_call(flags=32 | FLAG_GELU, y=hid, y_bstride=H * P, y_cstride=P, **common1)
+    img = torch.zeros(H // 8, N, 8, dtype=torch.int16, device="cuda")
+    conv_call(flags=32 | FLAG_GELU | 64, yh=img, yh_n=N, y_bstride=H * P, y_cstride=P, **common1)
+    hdt = torch.bfloat16 if mode == "bf16" else torch.float16
+    want_img = hid.permute(1, 0, 2).reshape(H // 8, 8, N).permute(0, 2, 1).to(hdt).contiguous().view(torch.int16)
+    assert torch.equal(img, want_img)
+    for M2 in (256, 128):                                # 256-row and 128-row tiles of the image-input kernel
+        W2, b2 = rnd(M2, H, seed=83, scale=0.2), rnd(M2, seed=84, scale=0.2)
+        wt2, bias2, _, Mpad2, K2, Kpad2, _ = pack_w(W2, b2, tile=128)
+        scale, res = pack_vec(rnd(M2, seed=85) + 1.0, Mpad2), rnd(B, M2, P, seed=86).float().cuda()
+        common2 = dict(wt=wt2, M=M2, Mpad=Mpad2, K=K2, Kpad=Kpad2, ktab=ktab(H, 1, 1, 1, 1, 0, 0, P, P, Kpad2), x=hid, x_bstride=H * P,
+                       B=B, D1=1, D2=P, O1=1, O2=P, S1=1, S2=1, bias=bias2, epi=EPI_LINEAR, flags=FLAG_SCALE | FLAG_RES, scale=scale, res=res,
+                       y_bstride=M2 * P, y_cstride=P, tile_m=128, plain=1, x6=mode)
+        y_ref, y_img = torch.empty(B, M2, P, device="cuda"), torch.empty(B, M2, P, device="cuda")
+        conv_call(y=y_ref, **common2)
+        conv_call(y=y_img, xh=img, xh_n=N, **common2)
+        assert maxerr(y_img, y_ref) < 1e-5
+
+
 @pytest.mark.parametrize("dtype", [0, 1, 2], ids=["f32", "bf16", "f16"])
 def test_attention_matches_softmax(lib, dtype):
     """softmax(QK^T/8)V per head on channel-first q/k/v, ragged Tq (not a multiple of 128), cross
