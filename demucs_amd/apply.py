@@ -349,11 +349,12 @@ def hdemucs_min_length() -> int:
 
 
 def _i64(values, device) -> torch.Tensor:
-    return torch.tensor(list(values), dtype=torch.int64, device=device)
+    # built on the host, ONE copy: torch.tensor(list, device=cuda) writes the elements one by one (a copy kernel each)
+    return torch.tensor(list(values), dtype=torch.int64).to(device)
 
 
 def _i32(values, device) -> torch.Tensor:
-    return torch.tensor(list(values), dtype=torch.int32, device=device)
+    return torch.tensor(list(values), dtype=torch.int32).to(device)
 
 
 def _is_engine(model) -> bool:
@@ -417,6 +418,10 @@ def device_split_accumulate(model: HTDemucs, base: torch.Tensor, chunk_offset: i
                                               cut_buf.data_ptr(), cut_buf.numel(), stream()), "mi_segments_gather")
             if short:
                 seg_buf[:nb, :, :valid_length] = cut_buf[:nb]
+            # the overlap-add's index tensors go to the device BEFORE the forward is enqueued: a host -> device copy issued
+            # behind it would hold the host (and the next launch) until the forward has drained
+            acc_offs = [o - acc_origin for o in offs]
+            t_offs, t_lens, t_trims = _i64(acc_offs, dev), _i32(lens, dev), _i32(trims, dev)
             if on_start is not None:
                 on_start(offs[0])
             model.forward_segments(seg_buf[:nb], out_buf[:nb])
@@ -429,8 +434,6 @@ def device_split_accumulate(model: HTDemucs, base: torch.Tensor, chunk_offset: i
                     on_start(o)
                 if on_end is not None:
                     on_end(o)
-            acc_offs = [o - acc_origin for o in offs]
-            t_offs, t_lens, t_trims = _i64(acc_offs, dev), _i32(lens, dev), _i32(trims, dev)
             # a segment may hang over either end of `acc` (a rank's slab of a shifted pass): only the part inside counts
             span_lo, span_hi = max(0, min(acc_offs)), min(acc.shape[1], max(a + n for a, n in zip(acc_offs, lens)))
             if span_hi <= span_lo:
@@ -515,14 +518,19 @@ def ragged_split_accumulate(model: HDemucs, base: torch.Tensor, chunk_offset: in
             keep = overlap_add(tail_out, [offsets[-1]], lens[-1])  # noqa: F841
 
 
+def finish_index(length: int, offsets: Sequence[int], segment_length: int, dev):
+    """(offsets, lengths) of ALL segments of a chunk on the device, for `device_split_finish`; built ahead of the forwards so
+    that the copy does not wait behind them."""
+    return _i64(offsets, dev), _i32([min(length - o, segment_length) for o in offsets], dev)
+
+
 def device_split_finish(acc: torch.Tensor, acc_origin: int, length: int, offsets: Sequence[int], segment_length: int,
-                        weight: torch.Tensor) -> None:
+                        weight: torch.Tensor, index=None) -> None:
     """`out /= sum_weight` on the device, sum_weight rebuilt from ALL segment offsets of the chunk."""
     lib = _lib.load()
     dev = acc.device
-    lens = [min(length - o, segment_length) for o in offsets]
     with torch.cuda.device(dev):
-        t_offs, t_lens = _i64(offsets, dev), _i32(lens, dev)
+        t_offs, t_lens = index if index is not None else finish_index(length, offsets, segment_length, dev)
         _lib.check(lib.mi_ola_finish(acc.data_ptr(), acc.shape[1], acc.shape[0], acc_origin, t_offs.data_ptr(),
                                      t_lens.data_ptr(), len(offsets), segment_length, weight.data_ptr(),
                                      C.c_void_p(_lib.current_stream_ptr())), "mi_ola_finish")
@@ -563,6 +571,7 @@ def _apply_split_device(model, mix, common, callback, callback_arg) -> torch.Ten
         first = b == 0
         base = chunk.tensor[b].to(device=device, dtype=torch.float32).contiguous()       # whole track resident in HBM
         acc = out[b].view(S * channels, length) if on_device else torch.zeros(S * channels, length, device=device, dtype=torch.float32)
+        fin = finish_index(length, offsets, segment_length, device)
         if ragged:
             listen = first and (callback is not None or bar is not None)     # no listener: the tail chunk may overlap the others
             ragged_split_accumulate(model, base, chunk.offset, length, offsets, segment_length, weight, acc,
@@ -570,7 +579,7 @@ def _apply_split_device(model, mix, common, callback, callback_arg) -> torch.Ten
         else:
             device_split_accumulate(model, base, chunk.offset, length, offsets, segment_length, valid_length, weight, acc, 0,
                                     on_start if first else None, on_end if first else None, draw_rng=first)
-        device_split_finish(acc, 0, length, offsets, segment_length, weight)
+        device_split_finish(acc, 0, length, offsets, segment_length, weight, fin)
         if not on_device:
             out[b] = acc.view(S, channels, length).to(mix.device)
     if bar is not None:
