@@ -468,14 +468,16 @@ def ragged_split_accumulate(model: HDemucs, base: torch.Tensor, chunk_offset: in
                                           seg.numel(), stream()), "mi_segments_gather")
         return seg, t_starts
 
-    def overlap_add(out, offs, n):
+    def ola_index(offs, n):          # built before the forward is enqueued (see device_split_accumulate)
+        return _i64(offs, dev), _i32([n] * len(offs), dev), _i32([0] * len(offs), dev)
+
+    def overlap_add(out, offs, n, idx):
         nb = len(offs)
-        t_offs, t_lens, t_trims = _i64(offs, dev), _i32([n] * nb, dev), _i32([0] * nb, dev)
+        t_offs, t_lens, t_trims = idx
         _lib.check(lib.mi_ola_accumulate(acc.data_ptr(), acc.shape[1], rows, out.data_ptr(), n, out.numel(),
                                          t_offs.data_ptr(), t_lens.data_ptr(), t_trims.data_ptr(), nb, offs[0],
                                          min(acc.shape[1], offs[-1] + n), weight.data_ptr(), weight.numel(), stream()),
                    "mi_ola_accumulate")
-        return t_offs, t_lens, t_trims
 
     with torch.cuda.device(dev):
         # A track's tail chunk is shorter than the others, so it cannot join their batch, and a forward of this architecture
@@ -490,6 +492,7 @@ def ragged_split_accumulate(model: HDemucs, base: torch.Tensor, chunk_offset: in
             side.wait_stream(main_stream)                 # `base` and whatever produced it
             with torch.cuda.stream(side):
                 tail_seg, tail_idx = gather([offsets[-1]], lens[-1])
+                tail_ola = ola_index([offsets[-1]], lens[-1])
                 tail_out = model(tail_seg, aux=True)
             n_main -= 1
         i = 0
@@ -500,6 +503,7 @@ def ragged_split_accumulate(model: HDemucs, base: torch.Tensor, chunk_offset: in
             offs = list(offsets[i:j])
             i = j
             seg, t_starts = gather(offs, n)
+            idx = ola_index(offs, n)
             if on_start is not None:
                 on_start(offs[0])
             out = model(seg)
@@ -510,12 +514,12 @@ def ragged_split_accumulate(model: HDemucs, base: torch.Tensor, chunk_offset: in
                     on_start(o)
                 if on_end is not None:
                     on_end(o)
-            keep = overlap_add(out, offs, n)                      # noqa: F841  (index tensors stay referenced until enqueued)
+            overlap_add(out, offs, n, idx)
         if side is not None:
             main_stream.wait_stream(side)
-            for t in (tail_seg, tail_idx, tail_out):
+            for t in (tail_seg, tail_idx, tail_out, *tail_ola):
                 t.record_stream(main_stream)                      # allocated under the side stream, consumed on this one
-            keep = overlap_add(tail_out, [offsets[-1]], lens[-1])  # noqa: F841
+            overlap_add(tail_out, [offsets[-1]], lens[-1], tail_ola)
 
 
 def finish_index(length: int, offsets: Sequence[int], segment_length: int, dev):
