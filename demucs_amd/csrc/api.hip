@@ -271,6 +271,15 @@ int mi_attention(const float *q_dev, const float *k_dev, const float *v_dev, flo
                             (hipStream_t)stream);
 }
 
+int mi_attention_image(const float *q_dev, const float *k_dev, const float *v_dev, void *img_dev, int64_t n_img, int32_t B,
+                       int32_t heads, int32_t Tq, int32_t Tk, int64_t q_batch_stride, int64_t kv_batch_stride, int32_t dtype,
+                       void *stream) {
+    MI_REQUIRE(q_dev && k_dev && v_dev && img_dev && B > 0 && heads > 0 && Tq > 0 && Tk > 0, "mi_attention_image: bad argument");
+    MI_REQUIRE(dtype == MI_DTYPE_BF16 || dtype == MI_DTYPE_F16, "mi_attention_image: dtype %d is not a half mode", dtype);
+    return launch_attention(q_dev, k_dev, v_dev, nullptr, B, heads, Tq, Tk, q_batch_stride, kv_batch_stride, 0, dtype,
+                            (hipStream_t)stream, img_dev, n_img);
+}
+
 int mi_gn_gelu(float *x_dev, int32_t B, int32_t C, int32_t C_alloc, int32_t D1, int32_t D2, int32_t row_mode, const float *stats_dev,
                const float *w_dev, const float *b_dev, void *stream) {
     MI_REQUIRE(x_dev && stats_dev && w_dev && b_dev && B > 0 && C > 0 && D1 > 0 && D2 > 0, "mi_gn_gelu: bad argument");

@@ -153,14 +153,15 @@ __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict_
 
 // gemm of the reduced-precision modes: attention_half.hip (built without the forced VGPR-form MFMA)
 int launch_attention_half(const float *q, const float *k, const float *v, float *o, int B, int heads, int Tq, int Tk, int64_t q_bs,
-                          int64_t kv_bs, int64_t o_bs, int dtype, hipStream_t st);
+                          int64_t kv_bs, int64_t o_bs, int dtype, hipStream_t st, void *oh, int64_t oh_n);
 
 int launch_attention(const float *q, const float *k, const float *v, float *o, int B, int heads, int Tq, int Tk, int64_t q_bs,
-                     int64_t kv_bs, int64_t o_bs, int dtype, hipStream_t st) {
+                     int64_t kv_bs, int64_t o_bs, int dtype, hipStream_t st, void *oh, int64_t oh_n) {
+    MI_REQUIRE(!oh || dtype != MI_DTYPE_F32, "attention: the operand-image output exists in the half modes only");
     MI_REQUIRE(Tk % 4 == 0, "attention: Tk %% 4 != 0 (%d)", Tk);
     MI_REQUIRE(((uintptr_t)k & 15) == 0 && ((uintptr_t)v & 15) == 0 && kv_bs % 4 == 0, "attention: k/v must be 16-byte aligned");
     MI_REQUIRE(dtype == MI_DTYPE_F32 || dtype == MI_DTYPE_BF16 || dtype == MI_DTYPE_F16, "attention: dtype %d", dtype);
-    if (dtype != MI_DTYPE_F32) return launch_attention_half(q, k, v, o, B, heads, Tq, Tk, q_bs, kv_bs, o_bs, dtype, st);
+    if (dtype != MI_DTYPE_F32) return launch_attention_half(q, k, v, o, B, heads, Tq, Tk, q_bs, kv_bs, o_bs, dtype, st, oh, oh_n);
     hipLaunchKernelGGL(attention_kernel, dim3(ceil_div(Tq, 128), heads, B), dim3(256), 0, st, q, k, v, o, Tq, Tk, q_bs, kv_bs, o_bs);
     MI_CHECK_LAUNCH();
     return MI_OK;

@@ -44,7 +44,7 @@ constexpr int VROW = KT / 8 + 1;     // V tile row pitch in 16-byte words (odd: 
 template <int HT>
 __global__ __launch_bounds__(256) void attention_half_kernel(const float *__restrict__ q, const float *__restrict__ k,
                                                              const float *__restrict__ v, float *__restrict__ o, int Tq, int Tk,
-                                                             int64_t q_bs, int64_t kv_bs, int64_t o_bs) {
+                                                             int64_t q_bs, int64_t kv_bs, int64_t o_bs, void *__restrict__ oh, int64_t oh_n) {
     __shared__ uint4 Ks[HD / 8][KT];         // [d octet][key] -> 8 consecutive d
     __shared__ uint4 Vs[HD][VROW];           // [d][key octet in accumulator-row order]
     {   // accumulators in AGPRs (see gemm_x6.hip)
@@ -163,7 +163,21 @@ __global__ __launch_bounds__(256) void attention_half_kernel(const float *__rest
     }
     const float ltot = lrun + __shfl_xor(lrun, 32);
     const float inv = 1.0f / ltot;
-    if (qok) {
+    if (qok && oh) {
+        // the output only feeds out_proj's matrix product: written as its 16-bit operand image [channel / 8][b * Tq + query][8]
+        // (gemm_half.hip: conv_gemm_half_img_kernel); four consecutive channels of a lane = one 8-byte store
+        uint2 *img = reinterpret_cast<uint2 *>(oh);
+        const size_t n = (size_t)b * Tq + qi;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const int oct = (head * HD + dt * 32 + 8 * rq) >> 3;
+                img[((size_t)oct * oh_n + n) * 2 + lh] =
+                    make_uint2(pack_half2(HT, oacc[dt][4 * rq] * inv, oacc[dt][4 * rq + 1] * inv),
+                               pack_half2(HT, oacc[dt][4 * rq + 2] * inv, oacc[dt][4 * rq + 3] * inv));
+            }
+    } else if (qok) {
         float *op = o + (size_t)b * o_bs + (size_t)head * HD * Tq + qi;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
@@ -176,12 +190,13 @@ __global__ __launch_bounds__(256) void attention_half_kernel(const float *__rest
 }
 
 int launch_attention_half(const float *q, const float *k, const float *v, float *o, int B, int heads, int Tq, int Tk, int64_t q_bs,
-                          int64_t kv_bs, int64_t o_bs, int dtype, hipStream_t st) {
+                          int64_t kv_bs, int64_t o_bs, int dtype, hipStream_t st, void *oh, int64_t oh_n) {
+    MI_REQUIRE(!oh || (oh_n >= (int64_t)B * Tq && ((uintptr_t)oh & 15) == 0), "attention: output image too small or misaligned");
     const dim3 grid(ceil_div(Tq, 128), heads, B);
     if (dtype == MI_DTYPE_BF16)
-        hipLaunchKernelGGL(attention_half_kernel<MI_DTYPE_BF16>, grid, dim3(256), 0, st, q, k, v, o, Tq, Tk, q_bs, kv_bs, o_bs);
+        hipLaunchKernelGGL(attention_half_kernel<MI_DTYPE_BF16>, grid, dim3(256), 0, st, q, k, v, o, Tq, Tk, q_bs, kv_bs, o_bs, oh, oh_n);
     else
-        hipLaunchKernelGGL(attention_half_kernel<MI_DTYPE_F16>, grid, dim3(256), 0, st, q, k, v, o, Tq, Tk, q_bs, kv_bs, o_bs);
+        hipLaunchKernelGGL(attention_half_kernel<MI_DTYPE_F16>, grid, dim3(256), 0, st, q, k, v, o, Tq, Tk, q_bs, kv_bs, o_bs, oh, oh_n);
     MI_CHECK_LAUNCH();
     return MI_OK;
 }

@@ -68,6 +68,18 @@ __device__ __forceinline__ float gelu_exact(float x) {
 }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// two floats -> two bf16 / fp16 values (round to nearest even) in one dword, `a` in the low half
+__device__ __forceinline__ unsigned pack_half2(int dtype, float a, float b) {
+    typedef __bf16 pk_bf16x2 __attribute__((ext_vector_type(2)));
+    typedef _Float16 pk_f16x2 __attribute__((ext_vector_type(2)));
+    if (dtype == 1 /* MI_DTYPE_BF16 */) {
+        const pk_bf16x2 h = {(__bf16)a, (__bf16)b};
+        return __builtin_bit_cast(unsigned, h);
+    }
+    const pk_f16x2 h = {(_Float16)a, (_Float16)b};
+    return __builtin_bit_cast(unsigned, h);
+}
+
 // packed fp32 math: v_pk_fma_f32 issues two IEEE fmas per lane per instruction (same results as two fmaf)
 typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }

@@ -48,18 +48,6 @@ __device__ __forceinline__ float gather_b(const mi_conv_desc &d, const mi_ktab_e
     return *p;
 }
 
-// two floats -> two bf16 / fp16 values (round to nearest even) in one dword, `a` in the low half
-__device__ __forceinline__ unsigned pack_half2(int dtype, float a, float b) {
-    typedef __bf16 pk_bf16x2 __attribute__((ext_vector_type(2)));
-    typedef _Float16 pk_f16x2 __attribute__((ext_vector_type(2)));
-    if (dtype == 1 /* MI_DTYPE_BF16 */) {
-        const pk_bf16x2 h = {(__bf16)a, (__bf16)b};
-        return __builtin_bit_cast(unsigned, h);
-    }
-    const pk_f16x2 h = {(_Float16)a, (_Float16)b};
-    return __builtin_bit_cast(unsigned, h);
-}
-
 // PLAIN = 1x1 / linear layer with K % 16 == 0 and (O1*O2) % 4 == 0: no gather table, float4 activation loads.
 // Epilogue shared by the register-staged and the LDS-DMA main loops.
 // acc[a][b][r] is C[m][n] with n = n0 + (wn*TN + b)*32 + li, m = m0 + (wm*TM + a)*32 + (r & 3) + 8 * (r >> 2) + 4 * lh

@@ -97,8 +97,9 @@ int launch_lstm_seq(const float *gx, const float *whh /* packed */, int N, int H
 int launch_local_attn(const float *qkc, int B, int C, int T, int ld /* row pitch of qkc, % 4 == 0 */, float *out, int ld_o, hipStream_t st);
 
 // attention.hip
+// oh != NULL (half modes): the output goes to a 16-bit operand image [512 / 8][oh_n][8] (column b * Tq + query) instead of o
 int launch_attention(const float *q, const float *k, const float *v, float *o, int B, int heads, int Tq, int Tk, int64_t q_bs,
-                     int64_t kv_bs, int64_t o_bs, int dtype, hipStream_t st);
+                     int64_t kv_bs, int64_t o_bs, int dtype, hipStream_t st, void *oh = nullptr, int64_t oh_n = 0);
 
 // ola.hip
 int launch_segments_gather(const float *track, int64_t track_len, int channels, const int64_t *starts_dev, int B, int valid,

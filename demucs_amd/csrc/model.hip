@@ -112,14 +112,16 @@ int Model::conv(const mi_conv_desc &d, hipStream_t st) {
 }
 
 int Model::attn(const float *q, const float *k, const float *v, float *o, int B, int Tq, int Tk, int64_t q_bs, int64_t kv_bs,
-                int64_t o_bs, hipStream_t st) {
-    if (!prof.on) return launch_attention(q, k, v, o, B, 8, Tq, Tk, q_bs, kv_bs, o_bs, cfg.dtype, st);
+                int64_t o_bs, hipStream_t st, bool image) {
+    void *oh = image ? (void *)o : nullptr;               // the image takes the place (half the bytes) of the float32 tensor
+    const int64_t oh_n = (int64_t)B * Tq;
+    if (!prof.on) return launch_attention(q, k, v, o, B, 8, Tq, Tk, q_bs, kv_bs, o_bs, cfg.dtype, st, oh, oh_n);
     const int cls = 100;
     // QK^T and PV: 2 * 2 * Tq * Tk * 64 flops per head; bytes = q, k, v read once + o written
     Profiler::Pending p{cls, prof.get(), prof.get(), 4.0 * B * 8 * (double)Tq * Tk * 64.0,
                         4.0 * B * 512.0 * (2.0 * Tq + 2.0 * Tk)};
     MI_HIP(hipEventRecord(p.a, st));
-    const int r = launch_attention(q, k, v, o, B, 8, Tq, Tk, q_bs, kv_bs, o_bs, cfg.dtype, st);
+    const int r = launch_attention(q, k, v, o, B, 8, Tq, Tk, q_bs, kv_bs, o_bs, cfg.dtype, st, oh, oh_n);
     MI_HIP(hipEventRecord(p.b, st));
     prof.pending.push_back(p);
     snprintf(prof.rows[cls].name, sizeof(prof.rows[cls].name), "attention%s_kernel", cfg.dtype == MI_DTYPE_BF16 ? "_bf16" : cfg.dtype == MI_DTYPE_F16 ? "_f16" : "");
@@ -690,13 +692,17 @@ int Model::run_tr_layer(int br, int k, int B, const float *x, const float2 *xsta
     float *qkv = w_tr_qkv[br], *att = w_tr_att[br], *x1 = w_tr_x1[br], *x2 = w_tr_x2[br], *ffh = w_tr_ffh[br];
     double *stats = br ? w_stats_t : w_stats;
     float2 *st1 = br ? w_st1_t : w_st1;
+    // half modes: tensors that only feed the next matrix product (attention output, FFN hidden) are written as that product's
+    // 16-bit operand image, in place of the float32 tensor, and consumed by the LDS-DMA main loop of gemm_half.hip
+    static const bool no_img = getenv("MI_NO_FFN_IMAGE") != nullptr;
+    const bool img = cfg.dtype != MI_DTYPE_F32 && !no_img;
     if (!cross) {
         mi_conv_desc d = base_desc(l.qkv_proj, tr_ktab512[br], x, (int64_t)512 * Tq, gq);
         d.plain = 1; d.epi = MI_EPI_LINEAR; d.flags = MI_FLAG_LN; d.scale = l.qkv_c1; d.pro_stats = (const float *)xstat;
         d.y = qkv; d.y_bstride = (int64_t)1536 * Tq; d.y_cstride = Tq;
         MI_TRY(conv(d, st));
         MI_TRY(attn(qkv, qkv + (size_t)512 * Tq, qkv + (size_t)1024 * Tq, att, B, Tq, Tq, (int64_t)1536 * Tq, (int64_t)1536 * Tq,
-                    (int64_t)512 * Tq, st));
+                    (int64_t)512 * Tq, st, img));
     } else {
         mi_conv_desc d = base_desc(l.q_proj, tr_ktab512[br], x, (int64_t)512 * Tq, gq);
         d.plain = 1; d.epi = MI_EPI_LINEAR; d.flags = MI_FLAG_LN; d.scale = l.q_c1; d.pro_stats = (const float *)xstat;
@@ -707,12 +713,13 @@ int Model::run_tr_layer(int br, int k, int B, const float *x, const float2 *xsta
         e.plain = 1; e.epi = MI_EPI_LINEAR; e.flags = MI_FLAG_LN; e.scale = l.kv_c1; e.pro_stats = (const float *)ostat;
         e.y = kv; e.y_bstride = (int64_t)1024 * Tk; e.y_cstride = Tk;
         MI_TRY(conv(e, st));
-        MI_TRY(attn(qkv, kv, kv + (size_t)512 * Tk, att, B, Tq, Tk, (int64_t)512 * Tq, (int64_t)1024 * Tk, (int64_t)512 * Tq, st));
+        MI_TRY(attn(qkv, kv, kv + (size_t)512 * Tk, att, B, Tq, Tk, (int64_t)512 * Tq, (int64_t)1024 * Tk, (int64_t)512 * Tq, st, img));
     }
     {   // x1 = x + gamma_1 * (out_proj(att) + b)
         mi_conv_desc d = base_desc(l.out_proj, tr_ktab512[br], att, (int64_t)512 * Tq, gq);
         d.plain = 1; d.epi = MI_EPI_LINEAR; d.flags = MI_FLAG_SCALE | MI_FLAG_RES; d.scale = l.gamma1; d.res = x;
         d.y = x1; d.y_bstride = (int64_t)512 * Tq; d.y_cstride = Tq;
+        if (img) { d.xh = att; d.xh_n = (int64_t)B * Tq; }
         MI_TRY(conv(d, st));
     }
     MI_TRY(launch_token_stats(x1, B, 512, Tq, w_tr_stat1[br], st));
@@ -721,10 +728,6 @@ int Model::run_tr_layer(int br, int k, int B, const float *x, const float2 *xsta
         d.plain = 1; d.epi = MI_EPI_LINEAR; d.flags = MI_FLAG_LN | MI_FLAG_GELU; d.scale = l.lin1_c1;
         d.pro_stats = (const float *)w_tr_stat1[br];
         d.y = ffh; d.y_bstride = (int64_t)2048 * Tq; d.y_cstride = Tq;
-        // half modes: the hidden tensor only ever feeds lin2's matrix product, so lin1 writes it as lin2's 16-bit operand
-        // image (into the same buffer) and lin2 moves both operands global -> LDS by DMA (gemm_half.hip)
-        static const bool no_img = getenv("MI_NO_FFN_IMAGE") != nullptr;
-        const bool img = d.half != 0 && !no_img;
         if (img) { d.flags |= MI_FLAG_IMG; d.yh = ffh; d.yh_n = (int64_t)B * Tq; }
         MI_TRY(conv(d, st));
         mi_conv_desc e = base_desc(l.lin2, tr_ktab2048[br], ffh, (int64_t)2048 * Tq, gq);

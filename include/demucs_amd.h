@@ -186,6 +186,14 @@ int mi_attention(const float *q_dev, const float *k_dev, const float *v_dev, flo
                  int32_t Tq, int32_t Tk, int64_t q_batch_stride, int64_t kv_batch_stride, int64_t o_batch_stride,
                  int32_t dtype, void *stream);
 
+/* mi_attention in a half mode with the result written as the 16-bit operand image of the projection that consumes it
+ *   (out_proj, demucs/transformer.py:418-419 inside nn.MultiheadAttention): img_dev[(heads * 64) / 8][n_img][8] bf16 / fp16,
+ *   column b * Tq + query, n_img >= B * Tq; element values are the float32 results of mi_attention rounded to nearest even.
+ *   Feeds mi_conv_desc.xh (demucs_amd/csrc/gemm_conv.h). */
+int mi_attention_image(const float *q_dev, const float *k_dev, const float *v_dev, void *img_dev, int64_t n_img, int32_t B,
+                       int32_t heads, int32_t Tq, int32_t Tk, int64_t q_batch_stride, int64_t kv_batch_stride, int32_t dtype,
+                       void *stream);
+
 /* In-place GroupNorm(1, C) + GELU of the first C channels of x (B, C_alloc, D1, D2) given per-row (mean, rstd) float2 statistics
  *   (row = b*D1 + d1 if row_mode else b): the norm/activation pair inside DConv (demucs/demucs.py:139). */
 int mi_gn_gelu(float *x_dev, int32_t B, int32_t C, int32_t C_alloc, int32_t D1, int32_t D2, int32_t row_mode, const float *stats_dev,

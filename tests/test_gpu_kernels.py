@@ -389,6 +389,15 @@ def test_attention_matches_softmax(lib, dtype):
     torch.cuda.synchronize()
     # half modes: Q, K, V and the probabilities are rounded to the operand type (2^-9 / 2^-12 relative), softmax in float32
     assert maxerr(o, want) < [2e-5, 6e-2, 8e-3][dtype]        # scores reach |s| ~ 30 at the spiked key: 2^-9 (2^-12) relative on them moves a probability by several percent
+    if dtype:
+        # the same result as out_proj's 16-bit operand image: exactly the rounding of the float32 output, [channel / 8][b Tq + q][8]
+        img = torch.zeros(512 // 8, B * Tq, 8, dtype=torch.int16, device="cuda")
+        _lib.check(lib.mi_attention_image(qd.data_ptr(), kv.data_ptr(), kv.data_ptr() + 512 * Tk * 4, img.data_ptr(), B * Tq, B, H, Tq, Tk,
+                                          512 * Tq, 1024 * Tk, dtype, stream()), "mi_attention_image")
+        torch.cuda.synchronize()
+        hdt = torch.bfloat16 if dtype == 1 else torch.float16
+        want_img = o.permute(1, 0, 2).reshape(64, 8, B * Tq).permute(0, 2, 1).to(hdt).contiguous().view(torch.int16)
+        assert torch.equal(img, want_img)
 
 
 def test_layernorm_channel_first(lib):
