@@ -46,6 +46,29 @@ class ToyModel:
         return torch.stack(outs, 1)
 
 
+class RaggedToy:
+    """Stand-in WITHOUT `valid_length` / `segment_length`, like the reference's HDemucs: the leaf forwards every chunk at its
+    own length, unpadded (demucs/apply.py:309-310); no RNG draw per forward."""
+    sources = ["a", "b", "c"]
+    samplerate = 100
+    audio_channels = 2
+    segment = Fraction(4, 1)
+
+    def to(self, device):
+        return self
+
+    def eval(self):
+        return self
+
+    def parameters(self):
+        yield torch.empty(0)
+
+    def __call__(self, mix):
+        n = mix.shape[-1]
+        ramp = torch.linspace(0.5, 1.5, n) * (1.0 + 0.001 * n)          # depends on the chunk length it was given
+        return torch.stack([torch.tanh((k + 1) * mix * ramp) + 0.01 * k for k in range(3)], 1)
+
+
 def both(model_p, model_o, mix, rseed=None, **kw):
     ev_p, ev_o = [], []
     if rseed is not None:
@@ -67,6 +90,14 @@ def test_split_matches_oracle_bit_exact(length, overlap, tp):
     assert torch.equal(mix, mix0)
     assert out_p.shape == (2, 3, 2, length) and torch.equal(out_p, out_o)
     assert ev_p == ev_o and len(ev_p) == 2 * len(range(0, length, int((1 - overlap) * 400)))
+
+
+@pytest.mark.parametrize("length,kw", [(1000, {}), (401, {}), (37, {}), (920, dict(segment=2.5)), (777, dict(shifts=2))])
+def test_model_without_valid_length_matches_oracle_bit_exact(length, kw):
+    mix = torch.randn(2, 2, length, generator=torch.Generator().manual_seed(length))
+    args = dict(dict(shifts=0, split=True, overlap=0.25), **kw)
+    out_p, out_o, ev_p, ev_o = both(RaggedToy(), RaggedToy(), mix, rseed=3, **args)
+    assert out_p.shape == (2, 3, 2, length) and torch.equal(out_p, out_o) and ev_p == ev_o
 
 
 def test_shifts_and_bag_match_oracle_bit_exact():

@@ -29,13 +29,15 @@ def _worker(rank, world, port, length, overlap, out_path, case):
     import random
     from demucs_amd import apply as P
     from demucs_amd.distributed import apply_model_sharded, no_sharding
-    from test_apply_host import ToyModel
+    from test_apply_host import RaggedToy, ToyModel
     batch = 2 if case == "batch2" else 1
     mix = torch.randn(batch, 2, length, generator=torch.Generator().manual_seed(7))
     events = []
-    if case in ("plain", "batch2"):
-        got = apply_model_sharded(ToyModel(), mix, overlap=overlap, callback=lambda d: events.append(dict(d)))
-        want = P.apply_model(ToyModel(), mix, shifts=0, split=True, overlap=overlap)
+    if case in ("plain", "batch2", "ragged"):
+        Toy = RaggedToy if case == "ragged" else ToyModel        # ragged: no valid_length, every chunk at its own length (HDemucs)
+        got = apply_model_sharded(Toy(), mix, overlap=overlap, callback=lambda d: events.append(dict(d)))
+        with no_sharding():
+            want = P.apply_model(Toy(), mix, shifts=0, split=True, overlap=overlap)
         ok = torch.equal(got, want)                        # single pass: bit-identical
         ok = ok and all(e["state"] in ("start", "end") for e in events) and len(events) % 2 == 0
     else:
@@ -66,7 +68,7 @@ def _worker(rank, world, port, length, overlap, out_path, case):
 
 
 @pytest.mark.parametrize("world,length,overlap,case", [
-    (2, 2500, 0.25, "plain"), (2, 300, 0.25, "plain"), (3, 4001, 0.1, "plain"), (2, 1700, 0.25, "batch2"),
+    (2, 2500, 0.25, "plain"), (2, 300, 0.25, "plain"), (3, 4001, 0.1, "plain"), (2, 1700, 0.25, "batch2"), (2, 1337, 0.25, "ragged"),
     (2, 2500, 0.25, "shifts"), (3, 3111, 0.25, "bag_shifts"), (2, 390, 0.25, "bag_shifts")])
 def test_sharded_equals_single_process(tmp_path, world, length, overlap, case):
     out_path = str(tmp_path / "res.pt")
@@ -74,7 +76,7 @@ def test_sharded_equals_single_process(tmp_path, world, length, overlap, case):
     res = torch.load(out_path)
     assert res["ok"], res
     assert res["shape"] == (2 if case == "batch2" else 1, 3, 2, length)
-    if case in ("plain", "batch2"):       # every segment fired its start/end pair on exactly one rank
+    if case in ("plain", "batch2", "ragged"):       # every segment fired its start/end pair on exactly one rank
         assert res["events"] == 2 * len(range(0, length, int((1 - overlap) * 400)))
 
 
