@@ -279,13 +279,16 @@ def main():
             hmix = make_mix(TRACK_SECONDS)
             P.apply_model(hbag, hmix, shifts=0, split=True, overlap=0.25, device=dev)
             torch.cuda.synchronize(dev)
-            t1 = time.perf_counter()
-            o = P.apply_model(hbag, hmix, shifts=0, split=True, overlap=0.25, device=dev)
-            torch.cuda.synchronize(dev)
-            dt_s = time.perf_counter() - t1
+            times = []
+            for _ in range(3):
+                t1 = time.perf_counter()
+                o = P.apply_model(hbag, hmix, shifts=0, split=True, overlap=0.25, device=dev)
+                torch.cuda.synchronize(dev)
+                times.append(time.perf_counter() - t1)
+            dt_s = sorted(times)[1]                       # median of three passes
             assert o.shape == (1, 4, 2, TRACK_SECONDS * SR) and bool(torch.isfinite(o[0, :, 0, ::997]).all())
             result["modes"]["hdemucs_mmi fp16"] = {"dtype": "f16", "sources": 4, "value": round(TRACK_SECONDS / dt_s, 2), "unit": "audio-sec/wall-sec",
-                                                   "ms_per_step": round(dt_s * 1e3, 2), "steps": 1,
+                                                   "ms_per_step": round(dt_s * 1e3, 2), "steps": 3,
                                                    "device_bytes": hm.device_bytes(),
                                                    "note": "6 chunks (overlap 0.25): five of 44 s in one batched forward, the 15 s tail on the side engine and a side stream under it"}
             del o, hmix
