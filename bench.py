@@ -79,6 +79,8 @@ def main():
     ap.add_argument("--no-host-leg", action="store_true")
     ap.add_argument("--no-fixed-leg", action="store_true")
     ap.add_argument("--no-modes-leg", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="run the N > 1 branch (RCCL process group, sharded apply_model with its "
+                    "collectives, max-over-ranks all_reduce) whatever WORLD_SIZE is: rehearses the multi-GPU code on one GPU")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -95,9 +97,14 @@ def main():
         args.gpus = world
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    multi = world > 1 or args.force_dist
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+    if args.force_dist:
+        from demucs_amd import distributed as _dd
+        _dd._forced = True
 
     cfg = HTDemucsConfig()
     sd = synthetic_state_dict(cfg, 0)
@@ -105,7 +112,7 @@ def main():
     model.load_state_dict(sd)
     model.to(dev).eval()
 
-    seconds = args.seconds or (TRACK_SECONDS if world == 1 else FIXED_SECONDS)
+    seconds = args.seconds or (FIXED_SECONDS if multi else TRACK_SECONDS)
     stride = int(0.75 * cfg.segment_length)
 
     def make_mix(secs):
@@ -117,7 +124,7 @@ def main():
         return P.apply_model(model, m, shifts=0, split=True, overlap=0.25, device=dev)
 
     def fence():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -143,7 +150,7 @@ def main():
     rows = model.profile_end()
     assert out.shape == (1, 4, 2, length) and out.device == dev and bool(torch.isfinite(out[0, 0, 0, ::997]).all())
     del out
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -176,16 +183,16 @@ def main():
             "metric": "real-time factor (audio-sec/wall-sec) htdemucs 4-stem 44.1kHz stereo, 1/8 GPU",
             "value": round(length / SR / sec_per_step, 2), "unit": "audio-sec/wall-sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(sec_per_step * 1e3, 3),
-            "higher_is_better": True, "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if multi else "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": (f"BASELINE configs[{1 if seconds == TRACK_SECONDS else 3}]: htdemucs 4-stem, {dtype_words}, "
                                     f"{seconds // 60}-min synthetic 44.1 kHz stereo track resident in HBM when the clock starts, stems "
                                     f"left in HBM, segment=7.8 s overlap=0.25 shifts=0, {n_segments} segments, {args.batch} segments "
                                     "per batched forward, random-init weights (synthetic_state_dict seed 0)"
                                     + ("; the SAME fixed track at every N > 1 (strong scaling); N = 1 of that curve is "
-                                       "`fixed_track` in the N = 1 line" if world > 1 else "")),
+                                       "`fixed_track` in the N = 1 line" if multi else "")),
                        "parallelism": (f"segments sharded over {world} GPUs by track interval, one RCCL all-gather of stem slabs per step"
-                                       if world > 1 else "one GPU")},
+                                       if multi else "one GPU")},
             "roofline": {"bound": bound, "kernel": dom["name"], "achieved": round(achieved, 2), "peak": peak,
                          "unit": unit, "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "pipe": ("bf16 MFMA, 6 products per fp32 MAC (exact 3-term operand split, fp32 accumulate)" if x6
@@ -199,7 +206,7 @@ def main():
                          "gbps": round(r["bytes"] / (r["ms"] * 1e-3) / 1e9, 1)} for r in sorted(rows, key=lambda r: -r["ms"])],
             "whole_path_tflops": round(FLOP_PER_SEGMENT * n_segments / sec_per_step / 1e12, 2),
         }
-        if world == 1 and not args.no_host_leg:
+        if not multi and not args.no_host_leg:
             # apply_model entry with the mix on the host -> stems materialised on the host
             host_mix = torch.empty(mix.shape, dtype=torch.float32, pin_memory=True)
             host_mix.copy_(mix)
@@ -216,7 +223,7 @@ def main():
                                       "runs": len(times), "span": "apply_model entry with a pinned host mix (63.5 MB H2D) -> the 254 MB of "
                                       "stems in a pinned host tensor (D2H), SURVEY.md 8(d); median"}
             del host_out, host_mix
-        if world == 1 and not args.no_fixed_leg and seconds != FIXED_SECONDS:
+        if not multi and not args.no_fixed_leg and seconds != FIXED_SECONDS:
             del mix
             torch.cuda.empty_cache()
             long_mix = make_mix(FIXED_SECONDS)
@@ -232,7 +239,7 @@ def main():
                                      "note": "configs[3]'s 60-minute track on ONE GPU, HBM-resident like `value`: the N = 1 point of the "
                                              "fixed-length (strong-scaling) curve that `--gpus N > 1` continues"}
             del o, long_mix
-        if world == 1 and not args.no_modes_leg and args.dtype == "f32":
+        if not multi and not args.no_modes_leg and args.dtype == "f32":
             # the reduced-precision compute modes on the same 3-minute track (BASELINE configs[2]'s bf16, configs[4]'s fp16 +
             # 6 sources): HBM-resident like `value`, own roofline against the dense bf16 / fp16 MFMA peak
             result["modes"] = {}
@@ -293,10 +300,10 @@ def main():
                                                    "note": "6 chunks (overlap 0.25): five of 44 s in one batched forward, the 15 s tail on the side engine and a side stream under it"}
             del o, hmix
             hm.release()
-        if world == 1 and not args.no_cpu_baseline:
+        if not multi and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(sd, cfg.sources)
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -70,6 +70,11 @@ SIGNATURES = {
                                     C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p]),
     "mi_ola_finish": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32,
                                 C.c_int32, C.c_void_p, C.c_void_p]),
+    "mi_mono_stats_scratch_bytes": (C.c_int32, []),
+    "mi_mono_stats": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mi_track_affine": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p]),
+    "mi_prevent_clip": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mi_two_stems": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]),
     "mi_stft_cac": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "mi_istft_cac": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "mi_conv_forward": (C.c_int, [C.POINTER(MiConvDesc), C.c_void_p]),

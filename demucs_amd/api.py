@@ -2,18 +2,27 @@
 
 Only what sits on the tensor -> tensor path is provided: construction around an already built
 model (the model zoo download of `demucs/pretrained.py` needs the network and is out of scope),
-`update_parameter`, `separate_tensor` with the reference's in-place normalise / restore contract
-(api.py:265-291), and the `samplerate / audio_channels / model` properties.  Audio file loading,
-resampling (`convert_audio`, julius) and stem writers are not part of this path.
+`update_parameter`, `separate_tensor` (api.py:241-291) and the `samplerate / audio_channels / model`
+properties.  Audio file loading and the stem writers are not part of this path.
+
+`separate_tensor` is a device path: ONE host -> device copy of the raw `wav`, the resampler kernel when `sr`
+differs (`convert_audio`, demucs_amd/audio.py), the mono mean / unbiased std by a device reduction
+(`mi_mono_stats`; the two scalars never visit the host), `(x - mean) / (std + 1e-8)` in place on the device
+copy (`mi_track_affine`), `apply_model` on device-resident tensors, `x * std + mean` in place on the stems,
+ONE device -> host copy of the stems into a pinned tensor.  The caller's host `wav` is never touched (the
+reference normalises it in place and restores it, which leaves rounding differences of ~1e-7 behind); a device
+`wav` is normalised and restored in place exactly as the reference does.
 """
 from __future__ import annotations
 
+import ctypes as C
 from typing import Callable, Dict, Optional, Tuple
 
 import torch
 
+from . import _lib
 from .audio import convert_audio
-from .apply import BagOfModels, apply_model
+from .apply import BagOfModels, _is_engine, _to_host, apply_model
 
 __all__ = ["Separator", "LoadModelError"]
 
@@ -61,6 +70,8 @@ class Separator:
     def separate_tensor(self, wav: torch.Tensor, sr: Optional[int] = None) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
         """api.py:241-291.  `wav` (channels, length) float32 is normalised IN PLACE by the mono
         mean / std for the duration of the call and restored before returning."""
+        if _is_engine(self._model) and torch.device(self._device).type == "cuda":
+            return self._separate_on_device(wav, sr)
         if sr is not None and sr != self._samplerate:
             wav = convert_audio(wav, sr, self._samplerate, self._audio_channels, device=self._device)
         ref = wav.mean(0)
@@ -77,6 +88,45 @@ class Separator:
         wav *= ref.std() + 1e-8
         wav += ref.mean()
         return wav, dict(zip(self._model.sources, out[0]))
+
+    def _separate_on_device(self, wav: torch.Tensor, sr: Optional[int]):
+        """The engine's `separate_tensor` (module docstring): everything between the one H2D and the one D2H runs on the GPU."""
+        device = torch.device(self._device)
+        if device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        lib = _lib.load()
+        host_in = wav.device.type == "cpu"
+        with torch.cuda.device(device):
+            stream = lambda: C.c_void_p(_lib.current_stream_ptr())          # noqa: E731
+            dev = wav.to(device=device, dtype=torch.float32, non_blocking=True) if host_in else wav
+            if sr is not None and sr != self._samplerate:
+                dev = convert_audio(dev, sr, self._samplerate, self._audio_channels, device=device)
+                if host_in:
+                    wav = None                    # the reference returns the converted tensor: handed back from the device below
+            if not dev.is_contiguous() or dev.dtype != torch.float32:
+                dev = dev.contiguous().float()
+            channels, length = dev.shape
+            scratch = torch.empty(lib.mi_mono_stats_scratch_bytes(), dtype=torch.uint8, device=device)
+            stats = torch.empty(2, dtype=torch.float32, device=device)
+            _lib.check(lib.mi_mono_stats(dev.data_ptr(), channels, length, scratch.data_ptr(), stats.data_ptr(), stream()),
+                       "mi_mono_stats")
+            restore = dev.clone() if (host_in and wav is None) else None       # resampled host input: returned un-normalised
+            _lib.check(lib.mi_track_affine(dev.data_ptr(), dev.numel(), stats.data_ptr(), 0, stream()), "mi_track_affine")
+            out = apply_model(self._model, dev[None], segment=self._segment, shifts=self._shifts, split=self._split,
+                              overlap=self._overlap, device=device, num_workers=self._jobs, callback=self._callback,
+                              callback_arg=_with(self._callback_arg, audio_length=length), progress=self._progress)
+            if out is None:
+                raise KeyboardInterrupt
+            out = out.contiguous()
+            _lib.check(lib.mi_track_affine(out.data_ptr(), out.numel(), stats.data_ptr(), 1, stream()), "mi_track_affine")
+            if host_in:
+                stems = _to_host(out, device)
+                if wav is None:
+                    wav = _to_host(restore, device)
+            else:
+                _lib.check(lib.mi_track_affine(dev.data_ptr(), dev.numel(), stats.data_ptr(), 1, stream()), "mi_track_affine")
+                stems, wav = out, dev
+        return wav, dict(zip(self._model.sources, stems[0]))
 
     @property
     def samplerate(self):

@@ -446,12 +446,13 @@ def device_split_accumulate(model: HTDemucs, base: torch.Tensor, chunk_offset: i
 def ragged_split_accumulate(model: HDemucs, base: torch.Tensor, chunk_offset: int, length: int, offsets: Sequence[int],
                             segment_length: int, weight: torch.Tensor, acc: torch.Tensor,
                             on_start: Optional[Callable[[int], None]] = None,
-                            on_end: Optional[Callable[[int], None]] = None) -> None:
+                            on_end: Optional[Callable[[int], None]] = None, acc_origin: int = 0, base_origin: int = 0) -> None:
     """`device_split_accumulate` for a model WITHOUT `valid_length` (HDemucs): the leaf forwards every chunk at its own
     length, unpadded (apply.py:309-310), so consecutive chunks of equal length -- all but the last of a track -- share one
     gather, one batched forward of up to `model.max_batch` chunks and one overlap-add; the shorter tail chunk gets its
     own, overlapped with the batched one on the model's side engine and stream when no listener needs ordered events.
-    Events fire in the reference's order (start, end, start, end ...), as in `device_split_accumulate`."""
+    Events fire in the reference's order (start, end, start, end ...), as in `device_split_accumulate`; `acc_origin` and
+    `base_origin` mean what they mean there (a multi-GPU rank's slab and its window of the track)."""
     lib = _lib.load()
     dev = base.device
     channels, total = base.shape
@@ -463,20 +464,24 @@ def ragged_split_accumulate(model: HDemucs, base: torch.Tensor, chunk_offset: in
 
     def gather(offs, n):
         seg = torch.empty(len(offs), channels, n, device=dev, dtype=torch.float32)
-        t_starts = _i64([chunk_offset + o for o in offs], dev)
+        t_starts = _i64([chunk_offset + o - base_origin for o in offs], dev)
         _lib.check(lib.mi_segments_gather(base.data_ptr(), total, channels, t_starts.data_ptr(), len(offs), n, seg.data_ptr(),
                                           seg.numel(), stream()), "mi_segments_gather")
         return seg, t_starts
 
     def ola_index(offs, n):          # built before the forward is enqueued (see device_split_accumulate)
-        return _i64(offs, dev), _i32([n] * len(offs), dev), _i32([0] * len(offs), dev)
+        return _i64([o - acc_origin for o in offs], dev), _i32([n] * len(offs), dev), _i32([0] * len(offs), dev)
 
     def overlap_add(out, offs, n, idx):
         nb = len(offs)
         t_offs, t_lens, t_trims = idx
+        # a chunk may hang over either end of `acc` (a rank's slab of a shifted pass): only the part inside counts
+        span_lo, span_hi = max(0, offs[0] - acc_origin), min(acc.shape[1], offs[-1] - acc_origin + n)
+        if span_hi <= span_lo:
+            return
         _lib.check(lib.mi_ola_accumulate(acc.data_ptr(), acc.shape[1], rows, out.data_ptr(), n, out.numel(),
-                                         t_offs.data_ptr(), t_lens.data_ptr(), t_trims.data_ptr(), nb, offs[0],
-                                         min(acc.shape[1], offs[-1] + n), weight.data_ptr(), weight.numel(), stream()),
+                                         t_offs.data_ptr(), t_lens.data_ptr(), t_trims.data_ptr(), nb, span_lo,
+                                         span_hi, weight.data_ptr(), weight.numel(), stream()),
                    "mi_ola_accumulate")
 
     with torch.cuda.device(dev):

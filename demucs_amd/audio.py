@@ -83,36 +83,63 @@ def convert_audio(wav: torch.Tensor, from_samplerate: int, to_samplerate: int, c
 
 
 # ---- after the separation: what demucs.separate does with the stems before any encoder sees them ----------------------
+_CLIP_MODES = {"rescale": 1, "clamp": 2, "tanh": 3}
+
+
+def _on_engine_device(t: torch.Tensor, what: str) -> torch.Tensor:
+    if t.device.type != "cuda":
+        raise _lib.EngineError(f"demucs_amd.audio.{what} only runs on device tensors (MI355X); got a {t.device} tensor. "
+                               "There is no CPU implementation in this package.")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{what}: float32 expected, got {t.dtype}")
+    return t.contiguous()
+
+
 def prevent_clip(wav: torch.Tensor, mode="rescale") -> torch.Tensor:
-    """demucs/audio.py:218-234, on whatever device the stems live (they stay in HBM with split=True on the engine)."""
+    """demucs/audio.py:218-234 on the stems' device (`mi_prevent_clip`: the peak of "rescale" is reduced on the device and
+    never visits the host).  The stems of an engine separation with `split=True` and a device mix live in HBM."""
     if mode is None or mode == "none":
         return wav
     assert wav.dtype.is_floating_point, "too late for clipping"
-    if mode == "rescale":
-        return wav / max(1.01 * wav.abs().max(), 1)
-    if mode == "clamp":
-        return wav.clamp(-0.99, 0.99)
-    if mode == "tanh":
-        return torch.tanh(wav)
-    raise ValueError(f"Invalid mode {mode}")
+    if mode not in _CLIP_MODES:
+        raise ValueError(f"Invalid mode {mode}")
+    x = _on_engine_device(wav, "prevent_clip")
+    y = torch.empty_like(x)
+    if x.numel():
+        with torch.cuda.device(x.device):
+            peak = torch.empty(1, dtype=torch.int32, device=x.device)
+            _lib.check(_lib.load().mi_prevent_clip(x.data_ptr(), x.numel(), _CLIP_MODES[mode], peak.data_ptr(), y.data_ptr(),
+                                                   C.c_void_p(_lib.current_stream_ptr())), "mi_prevent_clip")
+    return y
 
 
 def two_stems(origin: torch.Tensor, stems: dict, stem: str, other_method: str = "add") -> dict:
-    """`--two-stems STEM` of demucs/separate.py:189-218 as a tensor function: returns {STEM: ..., "no_STEM": sum of the
-    other stems} for other_method="add", {STEM: ..., "minus_STEM": origin - STEM} for "minus", {STEM: ...} for "none".
-    The sum runs in dict order from zeros, like the reference."""
+    """`--two-stems STEM` of demucs/separate.py:189-218 as a tensor function on the stems' device (`mi_two_stems`): returns
+    {STEM: ..., "no_STEM": 0 + the other stems in dict order} for other_method="add", {"minus_STEM": origin - STEM, STEM: ...}
+    for "minus", {STEM: ...} for "none"."""
     if stem not in stems:
         raise KeyError(f"stem {stem!r} is not in the separated sources {list(stems)}")
-    res = dict(stems)
-    out = {}
-    if other_method == "minus":
-        out["minus_" + stem] = origin - res[stem]
-    out[stem] = res.pop(stem)
-    if other_method == "add":
-        other = torch.zeros_like(next(iter(res.values())))
-        for v in res.values():
-            other += v
-        out["no_" + stem] = other
-    elif other_method not in ("minus", "none"):
+    if other_method not in ("add", "minus", "none"):
         raise ValueError(f"Invalid other_method {other_method}")
+    names = list(stems)
+    out = {}
+    if other_method in ("add", "minus"):
+        tensors = [_on_engine_device(stems[k], "two_stems") for k in names]
+        if len(tensors) > 8:
+            raise ValueError("two_stems: at most 8 stems")
+        n = tensors[0].numel()
+        assert all(t.numel() == n and t.device == tensors[0].device for t in tensors)
+        y = torch.empty_like(tensors[0])
+        minus = other_method == "minus"
+        org = _on_engine_device(origin, "two_stems") if minus else None
+        assert org is None or org.numel() == n
+        ptrs = (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+        with torch.cuda.device(y.device):
+            _lib.check(_lib.load().mi_two_stems(ptrs, len(tensors), names.index(stem), org.data_ptr() if minus else None, int(minus), n,
+                                                y.data_ptr(), C.c_void_p(_lib.current_stream_ptr())), "mi_two_stems")
+        if minus:
+            out["minus_" + stem] = y
+    out[stem] = stems[stem]
+    if other_method == "add":
+        out["no_" + stem] = y
     return out

@@ -208,6 +208,33 @@ int mi_ola_finish(float *acc_dev, int64_t acc_len, int32_t rows, int64_t acc_off
                              (hipStream_t)stream);
 }
 
+int32_t mi_mono_stats_scratch_bytes(void) { return post_stats_scratch_bytes(); }
+
+int mi_mono_stats(const float *wav_dev, int32_t channels, int64_t length, void *scratch_dev, float *stats_dev, void *stream) {
+    MI_REQUIRE(wav_dev && scratch_dev && stats_dev && channels >= 1 && length >= 1, "mi_mono_stats: bad argument");
+    return launch_mono_stats(wav_dev, channels, length, (double *)scratch_dev, stats_dev, (hipStream_t)stream);
+}
+
+int mi_track_affine(float *x_dev, int64_t numel, const float *stats_dev, int32_t inverse, void *stream) {
+    MI_REQUIRE(x_dev && stats_dev && numel >= 1 && (inverse == 0 || inverse == 1), "mi_track_affine: bad argument");
+    return launch_track_affine(x_dev, numel, stats_dev, inverse, (hipStream_t)stream);
+}
+
+int mi_prevent_clip(const float *x_dev, int64_t numel, int32_t mode, void *peak_dev, float *y_dev, void *stream) {
+    MI_REQUIRE(x_dev && y_dev && peak_dev && numel >= 1, "mi_prevent_clip: bad argument");
+    MI_REQUIRE(mode >= MI_CLIP_RESCALE && mode <= MI_CLIP_TANH, "mi_prevent_clip: unknown mode %d", mode);
+    return launch_prevent_clip(x_dev, numel, mode, (unsigned *)peak_dev, y_dev, (hipStream_t)stream);
+}
+
+int mi_two_stems(const float *const *stems_dev, int32_t n_stems, int32_t selected, const float *origin_dev, int32_t minus, int64_t numel,
+                 float *y_dev, void *stream) {
+    MI_REQUIRE(stems_dev && y_dev && n_stems >= 1 && n_stems <= 8 && selected >= 0 && selected < n_stems && numel >= 1,
+               "mi_two_stems: bad argument");
+    MI_REQUIRE(!minus || origin_dev, "mi_two_stems: the \"minus\" method needs the original mix");
+    for (int k = 0; k < n_stems; ++k) MI_REQUIRE(stems_dev[k], "mi_two_stems: null stem %d", k);
+    return launch_two_stems(stems_dev, n_stems, selected, origin_dev, minus ? 1 : 0, numel, y_dev, (hipStream_t)stream);
+}
+
 // Kernel-level entry points.  They allocate their scratch with hipMalloc and free it after a
 // stream synchronise: convenient for parity tests, not meant for the hot loop.
 int mi_stft_cac(const float *mix_dev, int32_t B, int32_t L, float *cac_dev, void *stream) {

@@ -29,13 +29,16 @@ struct HGeo {                   // everything that depends on the input length
     int L = 0, T = 0, Tp = 0, T5 = 0, Lt[6] = {}, Lp[6] = {};    // Tp: row pitch of the frequency-branch tensors (>= 32, multiple of 4)
     std::map<std::string, const mi_ktab_entry *> ktabs;
     DConvW enc_dconv[4], tenc_dconv[4];      // copies of the weights with this geometry's gather tables
+    uint64_t last_use = 0;                   // forward counter at the last use: the least recently used geometry is evicted
+    int64_t bytes = 0;                       // device bytes of `ktabs`
 };
 
 struct HModel : Model {
     int Lmax = 0, Tmax = 0;
     HEncW henc[6], htenc[5];
     HDecW hdec[6], htdec[5];
-    std::map<int, HGeo> geos;
+    std::map<int, HGeo> geos;              // at most kMaxGeos cached input lengths (LRU): every track's tail chunk and every
+    uint64_t use_clock = 0;                // random shift brings a new length, and a long-lived handle sees many tracks
     std::vector<void *> hws;     // workspace allocations (freed with the handle)
     int64_t hws_bytes = 0;
     // workspace
@@ -59,6 +62,7 @@ struct HModel : Model {
    private:
     int halloc(void **p, size_t bytes);
     int geometry(int L, HGeo **out);
+    void evict_lru();
     int ktab(HGeo &g, const Gather &ga, int Kpad, const mi_ktab_entry **out);
     int load_deep(const WeightTable &wt, const std::string &prefix, int C, HDeepLayerW *l, int d);
     int load_norm(const WeightTable &wt, const std::string &name, int C, float **w, float **b);

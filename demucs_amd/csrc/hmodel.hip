@@ -8,6 +8,7 @@
 // hidden width C/4 here); layers 4-5 (Fr = 1) add: GroupNorm(4) passes (row statistics + fused apply), the BLSTM
 // (chunk unfold -> input-gate GEMMs -> one persistent workgroup per sequence and direction -> re-stitch), LocalState
 // attention, and transposed convolutions whose GroupNorm statistics cover the UN-cropped output (hdemucs.py:325-333).
+#include <algorithm>
 #include <cmath>
 
 #include "hmodel.h"
@@ -15,8 +16,9 @@
 
 namespace mi {
 
-constexpr int kMinLength = 64;         // any chunk `apply_model` can produce in practice; frequency-branch rows carry a pitch >= 32
-                                       // frames (the row-statistics epilogues reduce 32 columns at a time) whatever the frame count
+constexpr int kMinLength = 1;          // the reference forwards chunks down to ONE sample (pad1d's zero-then-reflect rule); frequency-
+                                       // branch rows carry a pitch >= 32 frames (the row-statistics epilogues reduce 32 columns at a time)
+constexpr size_t kMaxGeos = 24;        // cached input lengths per handle (least recently used one evicted)
 static const int hFr[5] = {2048, 512, 128, 32, 8};
 static const int hCh[4] = {48, 96, 192, 384};
 
@@ -238,17 +240,37 @@ int HModel::ktab(HGeo &g, const Gather &ga, int Kpad, const mi_ktab_entry **out)
     auto it = g.ktabs.find(key);
     if (it == g.ktabs.end()) {
         mi_ktab_entry *t = nullptr;
+        const int64_t before = device_bytes;
         MI_TRY(make_ktab(ga, Kpad, &t));
+        g.bytes += device_bytes - before;
         it = g.ktabs.emplace(key, t).first;
     }
     *out = it->second;
     return MI_OK;
 }
 
+// Drops the least recently used geometry: its gather tables are freed (hipFree waits for the device, so no launch that
+// still reads them is in flight) and taken off the handle's allocation list.
+void HModel::evict_lru() {
+    auto victim = geos.end();
+    for (auto it = geos.begin(); it != geos.end(); ++it)
+        if (victim == geos.end() || it->second.last_use < victim->second.last_use) victim = it;
+    if (victim == geos.end()) return;
+    (void)hipDeviceSynchronize();
+    for (auto &kv : victim->second.ktabs) {
+        void *p = const_cast<mi_ktab_entry *>(kv.second);
+        auto a = std::find(allocs.begin(), allocs.end(), p);
+        if (a != allocs.end()) allocs.erase(a);
+        (void)hipFree(p);
+    }
+    device_bytes -= victim->second.bytes;
+    geos.erase(victim);
+}
+
 int HModel::geometry(int L, HGeo **out) {
     auto it = geos.find(L);
     if (it == geos.end()) {
-        MI_REQUIRE(geos.size() < 64, "too many distinct input lengths for one handle (64 geometries cached)");
+        while (geos.size() >= kMaxGeos) evict_lru();
         HGeo g;
         g.L = L; g.T = (L + 1023) / 1024; g.T5 = (g.T + 1) / 2; g.Tp = std::max(32, round_up(g.T, 4));
         g.Lt[0] = L;
@@ -276,6 +298,7 @@ int HModel::geometry(int L, HGeo **out) {
         }
         MI_HIP(hipDeviceSynchronize());
     }
+    it->second.last_use = ++use_clock;
     *out = &it->second;
     return MI_OK;
 }

@@ -114,4 +114,11 @@ int launch_ola_finish(float *acc, int64_t acc_len, int rows, int64_t acc_off0, c
 int launch_resample_frac(const float *x, int rows, int64_t L, const float *table, int old_sr, int new_sr, int width, float *y,
                          int64_t Lout, hipStream_t st);
 
+// post.hip: Separator normalisation, clip prevention, two-stems sums
+int post_stats_scratch_bytes();
+int launch_mono_stats(const float *wav, int channels, int64_t length, double *scratch, float *stats, hipStream_t st);
+int launch_track_affine(float *x, int64_t n, const float *stats, int mode, hipStream_t st);
+int launch_prevent_clip(const float *x, int64_t n, int mode, unsigned *peak, float *y, hipStream_t st);
+int launch_two_stems(const float *const *stems, int S, int sel, const float *origin, int mode, int64_t n, float *y, hipStream_t st);
+
 }  // namespace mi

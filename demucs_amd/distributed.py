@@ -16,7 +16,7 @@ the weighted overlap-add (apply.py:295-299), so:
   * ONE all-gather of the equally padded contribution slabs (RCCL over xGMI) per call, whatever
     the number of bag members and shifts; every rank adds the slabs into the full-track buffer in
     rank order.
-With a single pass (one model, shifts=0) the slabs are gathered un-normalised and divided after
+With a single pass of a plain model (no bag, shifts=0) the slabs are gathered un-normalised and divided after
 the stitch: with overlap <= 0.5 a sample is covered by at most two segments, so the float32
 result is then bit-identical to the single-GPU (and to the reference's sequential) order.  With
 several passes the seam samples between two ranks' slabs may differ from the single-GPU result in
@@ -37,11 +37,16 @@ import torch
 import torch.distributed as dist
 
 from . import apply as _apply
+from .hdemucs import HDemucs
 from .htdemucs import HTDemucs
 
-__all__ = ["shard_ranges", "apply_model_sharded", "no_sharding", "sharding_active", "track_intervals"]
+__all__ = ["shard_ranges", "apply_model_sharded", "no_sharding", "force_collectives", "sharding_active", "track_intervals",
+           "rng_draws_per_forward"]
 
 _enabled = os.environ.get("DEMUCS_AMD_SHARD", "1") != "0"
+# DEMUCS_AMD_SHARD=force: take the sharded route and execute every collective even in a process group of ONE rank, so that
+# the RCCL calls (broadcast, all_gather_into_tensor) run on a one-GPU box (tests/test_gpu_nccl.py, `bench.py --force-dist`)
+_forced = os.environ.get("DEMUCS_AMD_SHARD") == "force"
 
 
 @contextlib.contextmanager
@@ -55,8 +60,20 @@ def no_sharding():
         _enabled = old
 
 
+@contextlib.contextmanager
+def force_collectives():
+    """Inside this block the sharded route and its collectives run for ANY process group, a single rank included."""
+    global _forced
+    old, _forced = _forced, True
+    try:
+        yield
+    finally:
+        _forced = old
+
+
 def sharding_active(group=None) -> bool:
-    return _enabled and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    return (_enabled and dist.is_available() and dist.is_initialized()
+            and (dist.get_world_size(group) > 1 or _forced))
 
 
 def shard_ranges(n_items: int, world: int) -> List[Tuple[int, int]]:
@@ -81,6 +98,19 @@ def track_intervals(length: int, stride: int, world: int) -> List[Tuple[int, int
         b = offsets[hi] if hi < len(offsets) else length
         out.append((a, b))
     return out
+
+
+def rng_draws_per_forward(model) -> int:
+    """How many `random.randrange(1)`-sized draws one forward of `model` takes from Python's global RNG: the reference's
+    HTDemucs draws once in its transformer (transformer.py:680), its HDemucs draws nothing (hdemucs.py:689-794).  Any other
+    model object states it with an integer attribute `rng_draws_per_forward` (default 0).  A rank only runs its own
+    segments, so this is what keeps every rank's RNG stream -- and with it the shift offsets of the later passes -- equal
+    to a seeded single-process run."""
+    if isinstance(model, HTDemucs):
+        return 1
+    if isinstance(model, HDemucs):
+        return 0
+    return int(getattr(model, "rng_draws_per_forward", 0))
 
 
 def _agree_on(value: int, device, group) -> int:
@@ -130,30 +160,41 @@ def apply_model_sharded(model, mix: torch.Tensor, shifts: int = 0, overlap: floa
     slab_hi = [min(length, b + segment_length) if b > a else a for a, b in intervals]
     max_slab = max(h - l for l, h in zip(slab_lo, slab_hi))
     my_len = slab_hi[rank] - slab_lo[rank]
-    engine = all(isinstance(m, HTDemucs) for m in models) and device.type == "cuda"
+    # engine routes: "segments" = HTDemucs (every segment padded to the training length, one batched forward per max_batch
+    # segments), "ragged" = HDemucs (no valid_length: every chunk at its own length, equal chunks batched); anything else is
+    # a host model object on the generic per-segment route (CPU tests)
+    kinds = ["segments" if isinstance(m, HTDemucs) else "ragged" if isinstance(m, HDemucs) else "generic" for m in models]
+    engine = device.type == "cuda" and all(k != "generic" for k in kinds)
+    if not engine:
+        kinds = ["generic"] * len(models)
     weight = _apply._transition_weight(segment_length, transition_power, device).to(torch.float32).contiguous()
+    # one pass of one plain model: slabs are gathered un-normalised and divided after the stitch (bit-identical to one GPU);
+    # any shift (its virtual offsets differ from the un-shifted plan) or bag (per-source weights) takes the per-pass branch
+    single = n_pass == 1 and not shifts and not bag
 
     contrib = torch.zeros(batch, rows, max_slab, device=device, dtype=torch.float32)
     if engine:
-        valid = _apply._leaf_valid_length(models[0], segment_length, segment)
-        # this rank's window of the mix: every sample a padded segment window of any pass can touch
+        valid = max([_apply._leaf_valid_length(m, segment_length, segment) for m, k in zip(models, kinds) if k == "segments"],
+                    default=0)
+        # this rank's window of the mix: every sample a (padded) segment window of any pass can touch
         w_lo = max(0, i_lo - max_shift - valid)
-        w_hi = min(length, (length if rank == last_owner else i_hi) + 2 * valid)
+        w_hi = min(length, (length if rank == last_owner else i_hi + segment_length) + 2 * valid)
         window = mix[:, :, w_lo:w_hi].to(device=device, dtype=torch.float32).contiguous() if my_len else None
     else:
         padded_mix = _apply.tensor_chunk(mix).padded(length + 2 * max_shift)
 
-    for mi, (sub, sub_w) in enumerate(zip(models, bag_weights)):
+    for mi, (sub, sub_w, kind) in enumerate(zip(models, bag_weights, kinds)):
         sub.to(device)
         sub.eval()
+        draws = rng_draws_per_forward(sub)
         for si in range(n_shift):
             offset = random.randint(0, max_shift) if shifts else 0          # apply.py:245
-            if shifts and world > 1:
+            if shifts and (world > 1 or (_forced and dist.is_initialized())):
                 offset = _agree_on(offset, device, group)
             d = max_shift - offset                                          # virtual position v <-> track sample v - d
             lv = length + d                                                 # length of the shifted chunk
             offsets = list(range(0, lv, stride))
-            for _ in offsets:
+            for _ in range(draws * len(offsets)):
                 random.randrange(1)      # transformer.py:680 once per segment forward of the pass, on EVERY rank: seeded
                 #                          ranks stay in step with each other and with a seeded single-process run
             starts_t = [max(0, v - d) for v in offsets]
@@ -172,12 +213,17 @@ def apply_model_sharded(model, mix: torch.Tensor, shifts: int = 0, overlap: floa
                 first = b == 0
                 v0 = slab_lo[rank] + d                                       # virtual position of slab sample 0
                 part = torch.zeros(rows, my_len, device=device, dtype=torch.float32)
-                if engine:
+                listen = first and callback is not None
+                on_start, on_end = ((lambda v: fire("start", v)), (lambda v: fire("end", v))) if listen else (None, None)
+                if kind == "segments":
                     if mine:
                         _apply.device_split_accumulate(
-                            sub, window[b], -d, lv, mine, segment_length, valid, weight, part, v0,
-                            (lambda v: fire("start", v)) if first else None, (lambda v: fire("end", v)) if first else None,
-                            draw_rng=False, base_origin=w_lo)
+                            sub, window[b], -d, lv, mine, segment_length, _apply._leaf_valid_length(sub, segment_length, segment),
+                            weight, part, v0, on_start, on_end, draw_rng=False, base_origin=w_lo)
+                elif kind == "ragged":
+                    if mine:
+                        _apply.ragged_split_accumulate(sub, window[b], -d, lv, mine, segment_length, weight, part, on_start, on_end,
+                                                       acc_origin=v0, base_origin=w_lo)
                 else:
                     kw = dict(shifts=0, split=False, overlap=overlap, transition_power=transition_power, device=device,
                               segment=segment)
@@ -186,7 +232,7 @@ def apply_model_sharded(model, mix: torch.Tensor, shifts: int = 0, overlap: floa
                             chunk = _apply.TensorChunk(_apply.TensorChunk(padded_mix, offset, lv), v, segment_length)
                             if first:
                                 fire("start", v)
-                            state = random.getstate()                     # the leaf draws nothing the pass has not drawn above
+                            state = random.getstate()                     # the pass's draws were taken above, on every rank
                             out = _apply.apply_model(sub, chunk, **kw)[b].reshape(rows, -1).to(device)
                             random.setstate(state)
                             if first:
@@ -195,14 +241,14 @@ def apply_model_sharded(model, mix: torch.Tensor, shifts: int = 0, overlap: floa
                             lo = v - v0                                       # may be negative for the first shifted segment
                             a, c = max(lo, 0), min(lo + n, my_len)
                             part[:, a:c] += weight[a - lo:c - lo] * out[:, a - lo:c - lo]
-                if n_pass > 1:
+                if not single:
                     _normalise(part, v0, lv, offsets, segment_length, weight, engine)
                     contrib[b].view(S, channels, max_slab)[:, :, :my_len].add_(part.view(S, channels, my_len) * scale[:, None, None])
                 else:
                     contrib[b, :, :my_len] = part
                 del part
 
-    if world > 1:
+    if world > 1 or (_forced and dist.is_initialized()):
         gathered = torch.empty(world, batch, rows, max_slab, device=device, dtype=torch.float32)
         if dist.get_backend(group) == "nccl":
             dist.all_gather_into_tensor(gathered, contrib, group=group)    # ONE RCCL all-gather over xGMI
@@ -217,7 +263,7 @@ def apply_model_sharded(model, mix: torch.Tensor, shifts: int = 0, overlap: floa
         if s1 > s0:
             total[:, :, s0:s1] += gathered[r, :, :, :s1 - s0]
     del gathered
-    if n_pass == 1:
+    if single:
         offsets = list(range(0, length, stride))
         for b in range(batch):
             _normalise(total[b], 0, length, offsets, segment_length, weight, engine)

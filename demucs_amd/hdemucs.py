@@ -4,7 +4,7 @@ Mirrors what `apply_model` / `BagOfModels` / `Separator` use on the reference's 
 (reference: demucs/hdemucs.py:338-794): attributes `.sources .samplerate .audio_channels .segment`, NO `valid_length`
 (so the leaf hands every chunk over at its own length, demucs/apply.py:309-310), `to`, `eval`, `load_state_dict` /
 `state_dict` with the reference's key schema (395 tensors), and `__call__(mix)` mapping float32 `(B, 2, n)` on a GPU to
-`(B, S, 2, n)` for any n from 64 samples up (short inputs follow pad1d's zero-then-reflect rule, hdemucs.py:29-36).  One `mi_hmodel_forward` call per forward; no PyTorch
+`(B, S, 2, n)` for any n >= 1 (short inputs follow pad1d's zero-then-reflect rule, hdemucs.py:29-36).  One `mi_hmodel_forward` call per forward; no PyTorch
 implementation of the network exists in this package and there is no CPU path.
 """
 from __future__ import annotations
@@ -21,7 +21,7 @@ from .hdemucs_weights import HDemucsConfig, hdemucs_schema
 
 __all__ = ["HDemucs"]
 
-MIN_LENGTH = 64              # demucs_amd/csrc/hmodel.hip: kMinLength
+MIN_LENGTH = 1               # demucs_amd/csrc/hmodel.hip: kMinLength (the reference forwards any length >= 1 too)
 
 
 class HDemucs:
@@ -174,7 +174,7 @@ class HDemucs:
 
     # ---- forward --------------------------------------------------------------------------------------------------
     def __call__(self, mix: torch.Tensor, aux: bool = False) -> torch.Tensor:
-        """HDemucs.forward in eval mode (hdemucs.py:689-794): float32 (B, 2, n) -> (B, S, 2, n), any n >= 64.
+        """HDemucs.forward in eval mode (hdemucs.py:689-794): float32 (B, 2, n) -> (B, S, 2, n), any n >= 1.
         aux=True runs on the single-item side engine (its own workspace), so that it may overlap a forward of the main one
         on another stream; the results are the same bit for bit."""
         if mix.dim() != 3 or mix.shape[1] != self.audio_channels:

@@ -15,7 +15,7 @@ from typing import List, Tuple
 
 import numpy as np
 
-from .weights import _name_seed, counter_uniform
+from .weights import _name_seed, periodic_uniform
 
 __all__ = ["HDemucsConfig", "hdemucs_schema", "hdemucs_layer_plan", "synthetic_hdemucs_state_dict"]
 
@@ -184,12 +184,12 @@ def hdemucs_schema(cfg: HDemucsConfig) -> "OrderedDict[str, Tuple[int, ...]]":
     return out
 
 
-def synthetic_hdemucs_state_dict(cfg: HDemucsConfig, seed: int = 0) -> "OrderedDict[str, np.ndarray]":
+def synthetic_hdemucs_state_dict(cfg: HDemucsConfig, seed: int = 0, period=None) -> "OrderedDict[str, np.ndarray]":
     """Deterministic float32 weights keyed by tensor name; gains keep every stage O(1) (checked when the goldens are made)."""
     sd: "OrderedDict[str, np.ndarray]" = OrderedDict()
     for name, shape in hdemucs_schema(cfg).items():
         n = int(np.prod(shape))
-        u = counter_uniform(_name_seed(name, seed), n) * 2.0 - 1.0
+        u = periodic_uniform(_name_seed(name, seed), n, period) * 2.0 - 1.0
         leaf = name.rsplit(".", 1)[-1]
         if leaf == "scale":                                    # LayerScale: O(1), otherwise the DConv branch is invisible
             v = 1.0 + 0.5 * u

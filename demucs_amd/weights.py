@@ -24,7 +24,7 @@ from typing import Dict, List, Tuple
 import numpy as np
 
 __all__ = ["HTDemucsConfig", "htdemucs_schema", "synthetic_state_dict", "counter_uniform",
-           "counter_normal", "REFERENCE_DEFAULTS", "ENGINE_FIXED", "INERT_KEYWORDS", "check_reference_keyword"]
+           "counter_normal", "periodic_uniform", "REFERENCE_DEFAULTS", "ENGINE_FIXED", "INERT_KEYWORDS", "check_reference_keyword"]
 
 
 @dataclass
@@ -285,12 +285,20 @@ def _gain(name: str) -> float:
     return _GAINS["default"]
 
 
-def synthetic_state_dict(cfg: HTDemucsConfig, seed: int = 0) -> "OrderedDict[str, np.ndarray]":
+def periodic_uniform(seed: int, n: int, period=None) -> np.ndarray:
+    """`counter_uniform(seed, n)`, or with `period` its first `period` values repeated: a tensor filled this way deflates
+    ~200:1, which lets a full-size checkpoint package written by the reference live under tests/golden/ in ~1 MB."""
+    if period is None or n <= period:
+        return counter_uniform(seed, n)
+    return np.resize(counter_uniform(seed, period), n)
+
+
+def synthetic_state_dict(cfg: HTDemucsConfig, seed: int = 0, period=None) -> "OrderedDict[str, np.ndarray]":
     """Deterministic float32 weights keyed by tensor name (see module docstring)."""
     sd: "OrderedDict[str, np.ndarray]" = OrderedDict()
     for name, shape in htdemucs_schema(cfg).items():
         n = int(np.prod(shape))
-        u = counter_uniform(_name_seed(name, seed), n) * 2.0 - 1.0          # U(-1, 1)
+        u = periodic_uniform(_name_seed(name, seed), n, period) * 2.0 - 1.0          # U(-1, 1)
         leaf = name.rsplit(".", 1)[-1]
         if leaf == "scale":                                  # LayerScale: O(1)  (fact 8)
             v = 1.0 + 0.5 * u

@@ -150,6 +150,28 @@ int mi_ola_finish(float *acc_dev, int64_t acc_len, int32_t rows, int64_t acc_off
 int mi_resample_frac(const float *x_dev, int32_t rows, int64_t length, const float *table_dev, int32_t old_sr, int32_t new_sr,
                      int32_t width, float *y_dev, int64_t out_length, void *stream);
 
+/* ---- track-level pre / post processing of `Separator` and the CLI, on the device -------------------------------------------
+ * mi_mono_stats: `ref = wav.mean(0)`, then stats_dev[0] = ref.mean(), stats_dev[1] = ref.std() + 1e-8 (unbiased std;
+ *   demucs/api.py:267-269), float32 results of float64 accumulation in a fixed order.  wav_dev (channels, length);
+ *   scratch_dev: mi_mono_stats_scratch_bytes() bytes of device memory.  The scalars never visit the host.
+ * mi_track_affine: in place on x_dev (numel floats): inverse = 0: `x -= mean; x /= std` (api.py:268-269), inverse = 1:
+ *   `x *= std; x += mean` (api.py:285-288), each as two separately rounded float32 operations like the reference's. */
+int32_t mi_mono_stats_scratch_bytes(void);
+int mi_mono_stats(const float *wav_dev, int32_t channels, int64_t length, void *scratch_dev, float *stats_dev, void *stream);
+int mi_track_affine(float *x_dev, int64_t numel, const float *stats_dev, int32_t inverse, void *stream);
+
+/* mi_prevent_clip: `demucs.audio.prevent_clip(wav, mode)` (demucs/audio.py:218-234) on device stems: y = x / max(1.01 * max|x|, 1)
+ *   ("rescale"; the peak is reduced on the device into peak_dev, 4 bytes), clamp(x, -0.99, 0.99) or tanh(x).
+ * mi_two_stems: the `--two-stems` outputs of demucs/separate.py:189-218: minus = 0: y = 0 + (every stem but `selected`, in
+ *   index order) -- the "no_STEM" file; minus = 1: y = origin - stems[selected] -- the "minus_STEM" file.  stems_dev is a
+ *   HOST array of n_stems (<= 8) device pointers of numel floats each. */
+#define MI_CLIP_RESCALE 1
+#define MI_CLIP_CLAMP 2
+#define MI_CLIP_TANH 3
+int mi_prevent_clip(const float *x_dev, int64_t numel, int32_t mode, void *peak_dev, float *y_dev, void *stream);
+int mi_two_stems(const float *const *stems_dev, int32_t n_stems, int32_t selected, const float *origin_dev, int32_t minus, int64_t numel,
+                 float *y_dev, void *stream);
+
 /* ---- kernel-level entry points (parity tests; same kernels the forward uses) --------------
  * mi_stft_cac: `_magnitude(_spec(mix))` (demucs/htdemucs.py:420-461, demucs/spec.py:11-27):
  *   mix_dev (B,2,L) -> cac_dev (B,4,2048,ceil(L/1024)), channel order [c0.re,c0.im,c1.re,c1.im]. */

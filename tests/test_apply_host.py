@@ -17,6 +17,7 @@ class ToyModel:
     samplerate = 100
     audio_channels = 2
     segment = Fraction(4, 1)            # 400 samples
+    rng_draws_per_forward = 1           # like the reference's HTDemucs (transformer.py:680); read by the sharded scheduler
 
     def __init__(self, gain=1.0):
         self.gain = gain

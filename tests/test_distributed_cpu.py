@@ -42,16 +42,20 @@ def _worker(rank, world, port, length, overlap, out_path, case):
         ok = ok and all(e["state"] in ("start", "end") for e in events) and len(events) % 2 == 0
     else:
         w = [[1.0, 0.0, 0.5], [0.0, 1.0, 1.5]]
-        make = (lambda: P.BagOfModels([ToyModel(1.0), ToyModel(0.7)], w)) if case == "bag_shifts" else (lambda: ToyModel())
+        shifts = {"shift1": 1, "bag1_shift1": 1, "bag1_noshift": 0}.get(case, 2)
+        make = {"bag_shifts": lambda: P.BagOfModels([ToyModel(1.0), ToyModel(0.7)], w),
+                "bag1_shift1": lambda: P.BagOfModels([ToyModel(0.9)], [[0.5, 2.0, 1.25]]),      # one member, non-unit weights
+                "bag1_noshift": lambda: P.BagOfModels([ToyModel(0.9)], [[0.5, 2.0, 1.25]]),
+                "ragged_shifts": lambda: RaggedToy()}.get(case, lambda: ToyModel())
         if rank == 1:
             random.seed(99)        # ranks that were NOT seeded alike still agree on the shift offsets (rank 0's are used)
         else:
             random.seed(5)
-        got = apply_model_sharded(make(), mix, shifts=2, overlap=overlap, callback=lambda d: events.append(dict(d)))
+        got = apply_model_sharded(make(), mix, shifts=shifts, overlap=overlap, callback=lambda d: events.append(dict(d)))
         state_after = random.getstate()
         random.seed(5)
         with no_sharding():
-            want = P.apply_model(make(), mix, shifts=2, split=True, overlap=overlap)
+            want = P.apply_model(make(), mix, shifts=shifts, split=True, overlap=overlap)
         # several passes: identical up to the last bit at the seams between two ranks' slabs
         ok = bool((got - want).abs().max() <= 2e-6) and got.shape == want.shape
         if rank == 0:              # a seeded rank consumed exactly the draws of the single-process run
@@ -69,7 +73,11 @@ def _worker(rank, world, port, length, overlap, out_path, case):
 
 @pytest.mark.parametrize("world,length,overlap,case", [
     (2, 2500, 0.25, "plain"), (2, 300, 0.25, "plain"), (3, 4001, 0.1, "plain"), (2, 1700, 0.25, "batch2"), (2, 1337, 0.25, "ragged"),
-    (2, 2500, 0.25, "shifts"), (3, 3111, 0.25, "bag_shifts"), (2, 390, 0.25, "bag_shifts")])
+    (2, 2500, 0.25, "shifts"), (3, 3111, 0.25, "bag_shifts"), (2, 390, 0.25, "bag_shifts"),
+    # shifts=1 (the default of apply_model and Separator) and a one-member bag with non-unit weights must NOT take the
+    # single-pass shortcut; a model that draws nothing per forward (HDemucs) must not advance the RNG per segment
+    (2, 2500, 0.25, "shift1"), (3, 1777, 0.25, "shift1"), (2, 2100, 0.25, "bag1_shift1"), (2, 2100, 0.25, "bag1_noshift"),
+    (2, 1337, 0.25, "ragged_shifts"), (3, 2650, 0.25, "ragged_shifts")])
 def test_sharded_equals_single_process(tmp_path, world, length, overlap, case):
     out_path = str(tmp_path / "res.pt")
     mp.spawn(_worker, args=(world, _free_port(), length, overlap, out_path, case), nprocs=world, join=True)

@@ -49,35 +49,42 @@ def test_separator_resamples_then_separates():
         assert float((stems[k] - stems2[k]).abs().max()) < 1e-4
 
 
-def test_clip_prevention_and_two_stems_on_the_stems_device():
-    """SURVEY 8 f4, tensor half, on the GPU: the stems of an engine separation stay in HBM (device mix, split=True) and
-    `prevent_clip` / `two_stems` (demucs/audio.py:218-234, demucs/separate.py:189-218) run there; results equal the same
-    functions applied to host copies (bit-identical for rescale / clamp, last-bit for tanh), and the two-stems sum reconstructs the
-    sum of the other stems."""
-    from demucs_amd import apply as P
-    from demucs_amd.htdemucs import HTDemucs
-    from demucs_amd.synth import synth_mix
-    from demucs_amd.weights import HTDemucsConfig, synthetic_state_dict
-    cfg = HTDemucsConfig()
-    m = HTDemucs(cfg.sources, max_batch=2)
-    m.load_state_dict(synthetic_state_dict(cfg, 4))
-    mix = (torch.from_numpy(synth_mix(3, 400000, "tones"))[None] * 4.0).cuda()          # loud: the stems clip
-    out = P.apply_model(m, mix, shifts=0, overlap=0.25, device="cuda")
-    stems = dict(zip(cfg.sources, out[0]))
-    assert all(v.is_cuda for v in stems.values()) and float(out.abs().max()) > 1.0
-    for mode in ("rescale", "clamp", "tanh", None):
-        for k, v in stems.items():
-            got = audio.prevent_clip(v, mode)
-            want = audio.prevent_clip(v.cpu(), mode)
-            # rescale / clamp are exact float32 ops; the device tanh and the host tanh may differ in the last bit
-            assert got.is_cuda and (torch.allclose(got.cpu(), want, rtol=0, atol=2e-7) if mode == "tanh" else torch.equal(got.cpu(), want))
-        if mode in ("rescale", "clamp", "tanh"):
-            assert float(audio.prevent_clip(out, mode).abs().max()) <= 1.0
-    two = audio.two_stems(mix[0], stems, "vocals")
-    assert list(two) == ["vocals", "no_vocals"] and two["no_vocals"].is_cuda
-    want = torch.zeros_like(stems["drums"])
-    for k in ("drums", "bass", "other"):
-        want += stems[k]
-    assert torch.equal(two["no_vocals"], want)
-    minus = audio.two_stems(mix[0], stems, "vocals", "minus")
-    assert torch.equal(minus["minus_vocals"], mix[0] - stems["vocals"])
+def test_clip_prevention_and_two_stems_match_the_reference(golden):
+    """SURVEY 8 f4 on the GPU against the REFERENCE: tests/golden/clip_two_stems.npz holds `demucs.audio.prevent_clip` in its
+    three modes and the tensors the reference's `separate.main --two-stems vocals --other-method add|minus|none` hands to
+    `save_audio` (tools/make_golden.py clip_fixture runs that code with stand-in Separator / save_audio).  The device kernels
+    (`mi_prevent_clip`, `mi_two_stems`) must reproduce them: bit-exact for rescale / clamp / the sums, 2e-7 for tanh (libm)."""
+    import numpy as np
+    from conftest import GOLDEN
+    import os
+    z = np.load(os.path.join(GOLDEN, "clip_two_stems.npz"))
+    names = [str(n) for n in z["meta/sources"]]
+    stems = {k: torch.from_numpy(z[f"stem/{k}"]).cuda() for k in names}
+    origin = torch.from_numpy(z["origin"]).cuda()
+    for k in names + ["quiet"]:
+        x = torch.from_numpy(z[f"stem/{k}"]).cuda()
+        for mode in ("rescale", "clamp", "tanh"):
+            key = f"clip/{mode}/{k}"
+            if key not in z.files:
+                continue
+            got = audio.prevent_clip(x, mode)
+            want = torch.from_numpy(z[key])
+            assert got.is_cuda and got.shape == x.shape
+            if mode == "tanh":
+                assert float((got.cpu() - want).abs().max()) <= 2e-7
+            else:
+                assert torch.equal(got.cpu(), want), (mode, k, float((got.cpu() - want).abs().max()))
+        assert audio.prevent_clip(x, None) is x and audio.prevent_clip(x, "none") is x
+    assert float(torch.from_numpy(z["stem/vocals"]).abs().max()) > 1.0          # the fixture really clips
+    for method, extra in (("add", "no_vocals"), ("minus", "minus_vocals"), ("none", None)):
+        got = audio.two_stems(origin, stems, "vocals", method)
+        want_keys = sorted(k.split("/")[-1] for k in z.files if k.startswith(f"two_stems/{method}/"))
+        assert sorted(got) == want_keys, (sorted(got), want_keys)
+        for k, v in got.items():
+            assert v.is_cuda and torch.equal(v.cpu(), torch.from_numpy(z[f"two_stems/{method}/{k}"])), (method, k)
+    with pytest.raises(ValueError):
+        audio.prevent_clip(origin, "loud")
+    with pytest.raises(KeyError):
+        audio.two_stems(origin, stems, "kazoo")
+    with pytest.raises(Exception):
+        audio.prevent_clip(origin.cpu(), "clamp")             # no CPU implementation in this package

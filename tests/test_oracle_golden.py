@@ -145,7 +145,8 @@ from oracle import hdemucs_oracle as HO  # noqa: E402
 
 HSEG = {"hseg_tones_10s_w0": (0, lambda: synth_mix(21, 441000, "tones")),
         "hseg_noise_odd_w1": (1, lambda: synth_mix(22, 233731, "noise")),
-        "hseg_tiny_w0": (0, lambda: synth_mix(24, 1500, "tones"))}
+        "hseg_tiny_w0": (0, lambda: synth_mix(24, 1500, "tones")),
+        "hseg_10smp_w1": (1, lambda: synth_mix(25, 10, "noise"))}        # 10 samples: the reference forwards any length >= 1
 
 
 @pytest.mark.parametrize("name", list(HSEG))
@@ -170,13 +171,15 @@ def test_hdemucs_forward_matches_reference(golden, name, tag, dtype, atol):
     assert checked >= 23            # 6 enc + 6 dec + 5 tenc + 5 tdec + out
 
 
-def test_hdemucs_apply_model_matches_reference(golden):
+@pytest.mark.parametrize("name,mk", [("happly_10s_seg4", lambda: synth_mix(23, 449833, "tones")),
+                                     ("happly_tail10", lambda: synth_mix(26, 396910, "noise"))])      # tail chunk of 10 samples
+def test_hdemucs_apply_model_matches_reference(golden, name, mk):
     """apply_model around HDemucs: no valid_length, so every chunk runs at its own length (the last one shorter)."""
-    g = golden("happly_10s_seg4")
+    g = golden(name)
     cfg = HDemucsConfig()
     model = HO.OracleHDemucs(synthetic_hdemucs_state_dict(cfg, int(g.meta("wseed"))), cfg)
     kw = golden_kwargs(g)
-    mix = torch.from_numpy(synth_mix(23, 449833, "tones"))[None]
+    mix = torch.from_numpy(mk())[None]
     events = []
     out = A.apply_model(model, mix, callback=lambda d: events.append(dict(d)), **kw)
     g.check("f32", "out", out, atol=8e-5, rtol=8e-5)
@@ -184,3 +187,37 @@ def test_hdemucs_apply_model_matches_reference(golden):
     keys = ["model_idx_in_bag", "shift_idx", "segment_offset", "models", "state"]
     got = np.array([[str(e[k]) for k in keys] for e in events])
     assert got.shape == g.z["events"].shape and (got == g.z["events"]).all()
+
+
+# ---- checkpoint packages written by the reference ------------------------------------------------------
+def _package_state(path):
+    """The float16 state of a golden package as float32 numpy arrays (zip read with weights_only=True: nothing executed)."""
+    from demucs_amd import states
+    pkg = states.read_package(path)
+    return pkg, {k: v.float().numpy() for k, v in pkg["state"].items()}
+
+
+def test_oracle_on_reference_package_htdemucs(golden):
+    """The float64 oracle, fed the weights of the package the reference's `serialize_model` wrote, reproduces the forward of
+    the reference model re-loaded from that package."""
+    import os
+    from conftest import GOLDEN
+    g = golden("pkg_htdemucs")
+    _, sd = _package_state(os.path.join(GOLDEN, "pkg_htdemucs.th"))
+    mix = torch.from_numpy(synth_mix(31, int(g.meta("length")), "tones"))[None]
+    with torch.no_grad():
+        out = O.htdemucs_forward(O.to_torch_state(sd, torch.float64), mix.double(), 4)
+    g.check("f64", "out", out, atol=2e-9, rtol=2e-9)
+    g.check("f32", "out", out, atol=8e-5, rtol=8e-5)
+
+
+def test_oracle_on_reference_package_hdemucs(golden):
+    import os
+    from conftest import GOLDEN
+    g = golden("pkg_hdemucs")
+    _, sd = _package_state(os.path.join(GOLDEN, "pkg_hdemucs.th"))
+    mix = torch.from_numpy(synth_mix(32, int(g.meta("length")), "noise"))[None]
+    osd = {k: torch.from_numpy(v).double() for k, v in sd.items()}
+    with torch.no_grad():
+        out = HO.hdemucs_forward(osd, mix.double(), hdemucs_layer_plan(HDemucsConfig()), 4)
+    g.check("f64", "out", out, atol=2e-9, rtol=2e-9)

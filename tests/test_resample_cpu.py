@@ -51,23 +51,24 @@ def test_resample_needs_the_gpu_engine():
     assert audio.resample_frac(x, 44100, 44100, device="cpu") is x       # equal rates: no engine involved
 
 
-def test_prevent_clip_modes_and_two_stems():
-    """demucs/audio.py:218-234 and the --two-stems branch of demucs/separate.py:189-218."""
+def test_prevent_clip_and_two_stems_host_logic_without_a_gpu():
+    """demucs/audio.py:218-234 and the --two-stems branch of demucs/separate.py:189-218: the arithmetic runs in HIP kernels
+    (tests/test_gpu_resample.py checks it against the reference's fixture); here only what needs no device -- pass-through
+    modes, argument errors, and the loud refusal of host tensors (no CPU implementation)."""
+    from demucs_amd._lib import EngineError
     w = torch.tensor([[0.5, -2.0, 1.5]])
     assert audio.prevent_clip(w, None) is w and audio.prevent_clip(w, "none") is w
-    assert torch.allclose(audio.prevent_clip(w, "rescale"), w / (1.01 * 2.0))
-    assert torch.equal(audio.prevent_clip(w * 0.1, "rescale"), w * 0.1 / 1)            # quiet signals are left alone
-    assert torch.equal(audio.prevent_clip(w, "clamp"), torch.tensor([[0.5, -0.99, 0.99]]))
-    assert torch.equal(audio.prevent_clip(w, "tanh"), torch.tanh(w))
     with pytest.raises(ValueError):
         audio.prevent_clip(w, "loud")
+    with pytest.raises(EngineError):
+        audio.prevent_clip(w, "rescale")
     stems = {k: torch.full((2, 4), float(i + 1)) for i, k in enumerate(["drums", "bass", "other", "vocals"])}
     origin = sum(stems.values())
-    add = audio.two_stems(origin, stems, "vocals")
-    assert list(add) == ["vocals", "no_vocals"] and torch.equal(add["no_vocals"], torch.full((2, 4), 6.0))
-    minus = audio.two_stems(origin, stems, "vocals", "minus")
-    assert list(minus) == ["minus_vocals", "vocals"] and torch.equal(minus["minus_vocals"], origin - stems["vocals"])
     assert list(audio.two_stems(origin, stems, "bass", "none")) == ["bass"]
     assert set(stems) == {"drums", "bass", "other", "vocals"}                            # the caller's dict is not consumed
     with pytest.raises(KeyError):
         audio.two_stems(origin, stems, "piano")
+    with pytest.raises(ValueError):
+        audio.two_stems(origin, stems, "bass", "multiply")
+    with pytest.raises(EngineError):
+        audio.two_stems(origin, stems, "vocals", "add")

@@ -1,6 +1,9 @@
 """Checkpoint-package reader (demucs/states.py:50-107 -> demucs_amd/states.py).  No released checkpoint is available
-offline: the packages are written here in the reference's format (serialize_model, states.py:138-157), with a stand-in
-module `demucs.htdemucs` so that the pickled class reference carries the reference's qualified name.  Parity unpinned."""
+offline.  PINNED by `tests/golden/pkg_htdemucs.th` / `pkg_hdemucs.th`: full-size packages assembled by the reference's own
+`serialize_model` around reference models built with EVERY keyword of conf/config.yaml (tools/make_golden.py
+`package_fixture`; periodic weights, members re-stored deflated), and by `ref_signatures.json`, the reference constructors'
+keyword names and defaults.  The older cases write packages here in the same format with a stand-in module `demucs.htdemucs`
+so that the pickled class reference carries the reference's qualified name."""
 import sys
 import types
 import warnings
@@ -166,3 +169,88 @@ def test_hdemucs_packages_load_into_the_hdemucs_engine_class(tmp_path, fake_refe
         states.load_model({**pkg, "kwargs": {"hybrid": False}})
     with pytest.raises(ValueError):
         states.load_model({**pkg, "kwargs": {"depth": 5}})
+
+
+# ---- pinned by files the reference wrote (tools/make_golden.py package_fixture / signature_fixture) --------------------
+import json       # noqa: E402
+import os         # noqa: E402
+
+import numpy as np    # noqa: E402
+
+from conftest import GOLDEN    # noqa: E402
+
+
+@pytest.mark.parametrize("name", ["pkg_htdemucs", "pkg_hdemucs"])
+def test_reference_written_package_loads_without_warnings(name):
+    """`states.load_model` on the package the reference's serialize_model + torch.save produced: every one of the 62 / 35
+    keywords is understood (no "Dropping inexistant parameter" warning, nothing refused), the class maps to the engine class,
+    and the state equals the float16-rounded periodic fill the fixture was made from."""
+    from demucs_amd.hdemucs import HDemucs
+    from demucs_amd.hdemucs_weights import HDemucsConfig, synthetic_hdemucs_state_dict
+    path = os.path.join(GOLDEN, name + ".th")
+    meta = np.load(os.path.join(GOLDEN, name + ".npz"))
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        model = states.load_model(path)
+    assert not w, [str(x.message) for x in w]
+    pkg = states.read_package(path)
+    assert sorted(pkg["kwargs"]) == list(meta["meta/kwargs"]) and pkg["args"] == ()
+    assert all(v.dtype == torch.float16 for v in pkg["state"].values()) and len(pkg["state"]) == int(meta["meta/n_tensors"])
+    wseed, period = int(meta["meta/wseed"]), int(meta["meta/period"])
+    if name == "pkg_htdemucs":
+        assert isinstance(model, HTDemucs) and model.segment == Fraction(39, 5)
+        want = synthetic_state_dict(HTDemucsConfig(), wseed, period=period)
+    else:
+        assert isinstance(model, HDemucs) and model.segment == 40
+        want = synthetic_hdemucs_state_dict(HDemucsConfig(), wseed, period=period)
+    got = model.state_dict()
+    assert list(got) == list(want)
+    for k in list(want)[::7]:
+        assert torch.equal(torch.as_tensor(got[k]).float(), torch.from_numpy(want[k]).half().float()), k
+
+
+def test_keyword_tables_cover_the_reference_signatures():
+    """Every keyword of the reference constructors (inspect.signature, dumped by tools/make_golden.py) is classified by the
+    engine -- config field, inert in eval, or a fixed value -- and every default the engine fills in for an omitted keyword
+    equals the reference's default; the released configuration (conf/config.yaml) is accepted value by value."""
+    from demucs_amd import weights as W
+    from demucs_amd.hdemucs import HDemucs
+    from demucs_amd.hdemucs_weights import HDemucsConfig
+    with open(os.path.join(GOLDEN, "ref_signatures.json")) as f:
+        sig = json.load(f)
+
+    def value(v):
+        return Fraction(*v["Fraction"]) if isinstance(v, dict) and "Fraction" in v else v
+    # HTDemucs
+    fields = set(vars(HTDemucsConfig()))
+    ref = {k: value(v) for k, v in sig["HTDemucs"]}
+    for key, default in ref.items():
+        if key == "sources":
+            continue
+        if key in fields:
+            assert key in W.REFERENCE_DEFAULTS, f"HTDemucs config field {key} has no reference default recorded"
+            assert W.REFERENCE_DEFAULTS[key] == default, (key, W.REFERENCE_DEFAULTS[key], default)
+        else:
+            assert key in W.INERT_KEYWORDS or key in W.ENGINE_FIXED or key == "norm_starts", f"HTDemucs keyword {key} is unclassified"
+            if key in W.ENGINE_FIXED and key not in ("use_train_segment",):
+                # the reference's default of a forward-changing keyword must be the value the engine implements
+                assert W.check_reference_keyword(key, default), key
+    assert set(W.REFERENCE_DEFAULTS) <= set(ref), set(W.REFERENCE_DEFAULTS) - set(ref)
+    assert (set(W.INERT_KEYWORDS) | set(W.ENGINE_FIXED)) <= set(ref), (set(W.INERT_KEYWORDS) | set(W.ENGINE_FIXED)) - set(ref)
+    for key, v in sig["config.yaml"]["htdemucs"].items():          # the released configuration, value by value
+        if key not in fields:
+            assert W.check_reference_keyword(key, v), key
+    # HDemucs
+    hfields = set(vars(HDemucsConfig()))
+    href = {k: value(v) for k, v in sig["HDemucs"]}
+    cfg = HDemucsConfig()
+    for key, default in href.items():
+        if key == "sources":
+            continue
+        assert key in hfields or key in HDemucs._INERT or key in HDemucs._FIXED, f"HDemucs keyword {key} is unclassified"
+        if key in hfields:
+            assert getattr(cfg, key) == default, (key, getattr(cfg, key), default)
+        elif key in HDemucs._FIXED:
+            assert HDemucs._FIXED[key] == default or (key == "multi_freqs" and not default), (key, default)
+    assert (hfields - {"sources"}) | set(HDemucs._INERT) | set(HDemucs._FIXED) <= set(href)
+    HDemucs(**{**sig["config.yaml"]["hdemucs"], "sources": ["a", "b"], "audio_channels": 2, "samplerate": 44100, "segment": 40})

@@ -244,7 +244,186 @@ def happly_fixture(name: str, hcfg, wseed: int, mix: np.ndarray, **kw):
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **store)
 
 
+
+def hautocast_fixture(name: str, hcfg, wseed: int, mix: np.ndarray):
+    """`autocast_fixture` for the reference HDemucs: its float32 model under `torch.autocast("cpu", bf16 / fp16)` beside its
+    float64 run -- the noise floor the engine's reduced-precision hdemucs modes are scored against (BASELINE configs[4])."""
+    import_reference()
+    from demucs.hdemucs import HDemucs as RefHDemucs
+    from demucs_amd.hdemucs_weights import synthetic_hdemucs_state_dict
+    store = {"meta/wseed": np.array(wseed), "meta/n_sources": np.array(len(hcfg.sources)), "meta/length": np.array(mix.shape[-1])}
+    sd = synthetic_hdemucs_state_dict(hcfg, wseed)
+    x = torch.from_numpy(mix)[None]
+    for tag, dtype, cast in (("f64", torch.float64, None), ("bf16", torch.float32, torch.bfloat16), ("f16", torch.float32, torch.float16)):
+        model = RefHDemucs(sources=list(hcfg.sources))
+        model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()}, strict=True)
+        model = model.eval().to(dtype)
+        t0 = time.time()
+        with torch.no_grad():
+            if cast is None:
+                out = model(x.to(dtype))
+            else:
+                with torch.autocast("cpu", dtype=cast):
+                    out = model(x)
+        out = out.double()
+        print(f"  {name} {tag}: {time.time() - t0:.1f}s  out rms {out.pow(2).mean().sqrt():.4f}")
+        if tag == "f64":
+            truth = out
+        else:
+            err = out - truth
+            store[f"{tag}/max_abs"] = np.array(err.abs().max().item())
+            store[f"{tag}/sdr_db"] = np.array((10 * torch.log10((truth.pow(2).sum((2, 3)) + 1e-7) / (err.pow(2).sum((2, 3)) + 1e-7))).min().item())
+            print(f"    vs f64: max-abs {store[tag + '/max_abs']:.3e}  min SDR {store[tag + '/sdr_db']:.1f} dB")
+        pack(f"{tag}/out", sample(out, 16384), store)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **store)
+
+
+PACKAGE_PERIOD = 509          # weights repeat with this period (a prime): the package deflates ~200:1 (see periodic_uniform)
+
+
+def _reference_config(section: str) -> dict:
+    """Every keyword of one model section of the reference's conf/config.yaml (htdemucs: lines 195-271, hdemucs: 126-165)."""
+    import yaml
+    with open("/root/reference/conf/config.yaml") as f:
+        raw = dict(yaml.safe_load(f)[section])
+
+    def number(v):          # PyYAML reads `1e-3` (no dot) as a string; the reference's loader (omegaconf) reads a float
+        try:
+            return float(v) if isinstance(v, str) else v
+        except ValueError:
+            return v
+    return {k: number(v) for k, v in raw.items()}
+
+
+def package_fixture(name: str, kind: str, wseed: int, mix: np.ndarray):
+    """A checkpoint PACKAGE written by the reference's own code: the reference model is built with EVERY
+    keyword of its conf/config.yaml section passed explicitly (plus what demucs/train.py:38-60 adds and, for htdemucs, the
+    released-model overrides of grids/mmi.py), `demucs.states.serialize_model` (klass, args / kwargs from
+    `_init_args_kwargs`, `get_state(half=True)`) assembles it and `torch.save` writes it.  The zip members are then
+    re-stored deflated (same member bytes; `torch.load` reads either) so that the 84 / 167 MB file takes ~1 MB here.  Beside
+    it: forward samples of that reference model after `set_state` from the package (the half-rounded weights)."""
+    import zipfile
+    from fractions import Fraction
+    import_reference()
+    import demucs.states as ref_states
+    ref_states.OmegaConf = type("OmegaConf", (), {"to_container": staticmethod(lambda a, resolve=True: dict(a))})   # omegaconf is absent
+    if kind == "htdemucs":
+        from demucs.htdemucs import HTDemucs as Klass
+        cfg = HTDemucsConfig()
+        kwargs = _reference_config("htdemucs")
+        kwargs.update(dconv_mode=3, bottom_channels=512, t_dropout=0.02)                     # demucs/grids/mmi.py:15-30
+        kwargs.update(sources=list(cfg.sources), audio_channels=2, samplerate=44100, segment=Fraction(39, 5))
+        sd = synthetic_state_dict(cfg, wseed, period=PACKAGE_PERIOD)
+    else:
+        from demucs.hdemucs import HDemucs as Klass
+        from demucs_amd.hdemucs_weights import HDemucsConfig, synthetic_hdemucs_state_dict
+        cfg = HDemucsConfig()
+        kwargs = _reference_config("hdemucs")
+        kwargs.update(sources=list(cfg.sources), audio_channels=2, samplerate=44100, segment=40)   # train.py: 4 * dset.segment
+        sd = synthetic_hdemucs_state_dict(cfg, wseed, period=PACKAGE_PERIOD)
+    model = Klass(**kwargs)
+    model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()}, strict=True)
+    package = ref_states.serialize_model(model, {"fixture": name, "epochs": 0}, quantizer=None, half=True)
+    assert package["args"] == () and set(package["kwargs"]) == set(kwargs)
+    raw = os.path.join(OUT, name + ".raw.th")
+    torch.save(package, raw)
+    with zipfile.ZipFile(raw) as zin, zipfile.ZipFile(os.path.join(OUT, name + ".th"), "w", zipfile.ZIP_DEFLATED, compresslevel=9) as zout:
+        for info in zin.infolist():
+            zout.writestr(info.filename, zin.read(info.filename))
+    raw_size = os.path.getsize(raw)
+    os.remove(raw)
+    store = {"meta/wseed": np.array(wseed), "meta/period": np.array(PACKAGE_PERIOD), "meta/length": np.array(mix.shape[-1]),
+             "meta/kwargs": np.array(sorted(kwargs)), "meta/n_tensors": np.array(len(package["state"]))}
+    print(f"  {name}: {len(kwargs)} keywords, {len(package['state'])} tensors, {raw_size / 1e6:.0f} MB -> "
+          f"{os.path.getsize(os.path.join(OUT, name + '.th')) / 1e6:.2f} MB deflated")
+    for tag, dtype in (("f32", torch.float32), ("f64", torch.float64)):
+        # the reference's own loader on the fixture (its torch.load predates the weights_only default: the file written
+        # a few lines up is opened here and handed over as the package dict)
+        m = ref_states.load_model(torch.load(os.path.join(OUT, name + ".th"), map_location="cpu", weights_only=False)).eval().to(dtype)
+        with torch.no_grad():
+            out = m(torch.from_numpy(mix).to(dtype)[None])
+        print(f"  {name} {tag}: out rms {out.pow(2).mean().sqrt():.4f}")
+        pack(f"{tag}/out", sample(out, 16384), store)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **store)
+
+
+def signature_fixture(name: str):
+    """Names and defaults of the reference constructors' keywords (inspect.signature of HTDemucs / HDemucs `__init__`) as
+    JSON: tests compare the engine's keyword tables (weights.py, hdemucs.py) with it mechanically."""
+    import inspect
+    import json
+    from fractions import Fraction
+    import_reference()
+    from demucs.hdemucs import HDemucs
+    from demucs.htdemucs import HTDemucs
+
+    def plain(v):
+        if v is inspect.Parameter.empty:
+            return "<required>"
+        if isinstance(v, Fraction):
+            return {"Fraction": [v.numerator, v.denominator]}
+        return v
+    out = {}
+    for klass in (HTDemucs, HDemucs):
+        params = list(inspect.signature(klass.__init__).parameters.values())[1:]
+        out[klass.__name__] = [[p.name, plain(p.default)] for p in params]
+    out["config.yaml"] = {k: _reference_config(k) for k in ("htdemucs", "hdemucs")}
+    with open(os.path.join(OUT, name + ".json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=False)
+    print(f"  {name}: HTDemucs {len(out['HTDemucs'])} keywords, HDemucs {len(out['HDemucs'])}")
+
+
+def clip_fixture(name: str):
+    """`demucs.audio.prevent_clip` in its three modes, and the `--two-stems` arithmetic of
+    demucs/separate.py:189-218 obtained by RUNNING the reference's `separate.main` with its `Separator` and `save_audio`
+    names swapped for stand-ins that hand over fixed stems and capture what would be written (no audio codec exists here)."""
+    import tempfile
+    import_reference()
+    import demucs.audio as ref_audio
+    import demucs.separate as ref_sep
+    L = 6000
+    names = ["drums", "bass", "other", "vocals"]
+    stems = {k: torch.from_numpy(synth_mix(70 + i, L, "tones" if i % 2 else "noise")) * (0.4 + 0.5 * i) for i, k in enumerate(names)}
+    origin = sum(stems.values()) + 0.01 * torch.from_numpy(synth_mix(79, L, "noise"))
+    store = {"meta/length": np.array(L), "meta/sources": np.array(names), "origin": origin.numpy()}
+    for k, v in stems.items():
+        store[f"stem/{k}"] = v.numpy()
+        for mode in ("rescale", "clamp", "tanh"):
+            store[f"clip/{mode}/{k}"] = ref_audio.prevent_clip(v, mode).numpy()
+    quiet = stems["drums"] * 0.1                     # below full scale: "rescale" divides by max(1.01 * peak, 1) = 1
+    store["stem/quiet"] = quiet.numpy()
+    store["clip/rescale/quiet"] = ref_audio.prevent_clip(quiet, "rescale").numpy()
+
+    class FakeSeparator:
+        samplerate, audio_channels = 44100, 2
+        model = type("M", (), {"sources": names})()
+
+        def __init__(self, *a, **k):
+            pass
+
+        def separate_audio_file(self, track):
+            return origin.clone(), {k: v.clone() for k, v in stems.items()}
+    saved = {}
+    real = ref_sep.Separator, ref_sep.save_audio
+    ref_sep.Separator = FakeSeparator
+    ref_sep.save_audio = lambda wav, path, **kw: saved.__setitem__(os.path.basename(path), wav.clone())
+    try:
+        with tempfile.TemporaryDirectory() as tmp:
+            track = os.path.join(tmp, "song.wav")
+            open(track, "wb").close()
+            for method in ("add", "minus", "none"):
+                saved.clear()
+                ref_sep.main(["--two-stems", "vocals", "--other-method", method, "-o", os.path.join(tmp, method), track])
+                for fname, wav in saved.items():
+                    store[f"two_stems/{method}/{fname.rsplit('.', 1)[0]}"] = wav.numpy()
+                print(f"  {name} two-stems {method}: {sorted(saved)}")
+    finally:
+        ref_sep.Separator, ref_sep.save_audio = real
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **store)
+
+
 def main():
+    global hautocast_fixture, package_fixture, signature_fixture, clip_fixture
     global segment_fixture, apply_fixture, separator_fixture, autocast_fixture, hsegment_fixture, happly_fixture
     only = set(sys.argv[1:])
     if only:                                   # regenerate just the named fixtures
@@ -258,6 +437,11 @@ def main():
         happly_fixture = lambda n, *a, **k: ha_all(n, *a, **k) if n in only else None       # noqa: E731
         sep_all = separator_fixture
         separator_fixture = lambda n, *a, **k: sep_all(n, *a, **k) if n in only else None   # noqa: E731
+        hac_all, pk_all, sg_all, cl_all = hautocast_fixture, package_fixture, signature_fixture, clip_fixture
+        hautocast_fixture = lambda n, *a, **k: hac_all(n, *a, **k) if n in only else None   # noqa: E731
+        package_fixture = lambda n, *a, **k: pk_all(n, *a, **k) if n in only else None      # noqa: E731
+        signature_fixture = lambda n, *a, **k: sg_all(n, *a, **k) if n in only else None    # noqa: E731
+        clip_fixture = lambda n, *a, **k: cl_all(n, *a, **k) if n in only else None         # noqa: E731
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     cfg4 = HTDemucsConfig()
@@ -295,6 +479,15 @@ def main():
     # 449 833 samples, 4 s segments: chunks of 176 400 samples and a last one of 52 933 (T = 52 frames, odd length)
     hsegment_fixture("hseg_tiny_w0", hcfg, 0, synth_mix(24, 1500, "tones"))               # 2 frames: pad1d's zero-then-reflect rule
     happly_fixture("happly_10s_seg4", hcfg, 0, synth_mix(23, 449833, "tones"), shifts=0, split=True, overlap=0.25, segment=4)
+    hsegment_fixture("hseg_10smp_w1", hcfg, 1, synth_mix(25, 10, "noise"))                # 10 samples: everything collapses to one position
+    # stride 132 300: three full 4-second chunks and a TAIL CHUNK OF 10 SAMPLES (396 910 = 3 * 132 300 + 10)
+    happly_fixture("happly_tail10", hcfg, 1, synth_mix(26, 396910, "noise"), shifts=0, split=True, overlap=0.25, segment=4)
+    hautocast_fixture("hautocast_10s_w0", hcfg, 0, synth_mix(21, 441000, "tones"))
+    print("checkpoint package / keyword / clip fixtures")
+    package_fixture("pkg_htdemucs", "htdemucs", 5, synth_mix(31, 150000, "tones"))
+    package_fixture("pkg_hdemucs", "hdemucs", 6, synth_mix(32, 88200, "noise"))
+    signature_fixture("ref_signatures")
+    clip_fixture("clip_two_stems")
     print("separator fixtures")
     # a loud, DC-shifted input so that the mono mean / std normalisation of api.py:267-269 is far from the identity
     separator_fixture("separator_shift1", cfg4, 3, 3.0 * synth_mix(12, int(1.3 * SL), "tones") + 0.2, rseed=11,
