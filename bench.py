@@ -222,7 +222,26 @@ def main():
             result["host_to_host"] = {"value": round(length / SR / med, 2), "unit": "audio-sec/wall-sec", "ms_per_step": round(med * 1e3, 3),
                                       "runs": len(times), "span": "apply_model entry with a pinned host mix (63.5 MB H2D) -> the 254 MB of "
                                       "stems in a pinned host tensor (D2H), SURVEY.md 8(d); median"}
-            del host_out, host_mix
+            # the user-facing entry (demucs/api.py:241-291): Separator.separate_tensor with the raw host wav -- H2D, mono mean / std
+            # reduction, normalise, apply_model, de-normalise, D2H, all on the device between the two copies
+            from demucs_amd.api import Separator
+            sep = Separator(model, device=dev, shifts=0, overlap=0.25, split=True)
+            wav = host_mix[0]
+            sep.separate_tensor(wav)
+            times = []
+            for _ in range(max(3, min(args.steps, 7))):
+                t1 = time.perf_counter()
+                _, stems = sep.separate_tensor(wav)
+                times.append(time.perf_counter() - t1)
+            assert all(v.device.type == "cpu" and v.shape == (2, length) for v in stems.values())
+            med_s = statistics.median(times)
+            result["separator_host_to_host"] = {"value": round(length / SR / med_s, 2), "unit": "audio-sec/wall-sec",
+                                                "ms_per_step": round(med_s * 1e3, 3), "runs": len(times),
+                                                "vs_host_to_host": round(med / med_s, 4),
+                                                "span": "demucs_amd.api.Separator.separate_tensor(host wav) -> dict of host stems: the "
+                                                        "host_to_host span plus the mono mean / std reduction and the two affine passes, "
+                                                        "all device kernels (mi_mono_stats, mi_track_affine); median"}
+            del host_out, host_mix, stems, wav
         if not multi and not args.no_fixed_leg and seconds != FIXED_SECONDS:
             del mix
             torch.cuda.empty_cache()
