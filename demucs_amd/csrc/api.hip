@@ -298,6 +298,15 @@ int mi_attention(const float *q_dev, const float *k_dev, const float *v_dev, flo
                             (hipStream_t)stream);
 }
 
+int mi_attention_heads(const void *q_dev, const void *k_dev, const void *v_dev, float *o_dev, int32_t B, int32_t heads, int32_t Tq, int32_t Tk,
+                       int32_t Tq_pitch, int32_t Tk_pitch, int32_t dtype, void *stream) {
+    MI_REQUIRE(q_dev && k_dev && v_dev && o_dev && B > 0 && heads > 0 && Tq > 0 && Tk > 0, "mi_attention_heads: bad argument");
+    const void *zero = conv_zero_page();
+    MI_REQUIRE(zero, "mi_attention_heads: could not allocate the zero page");
+    return launch_attention_heads(q_dev, k_dev, v_dev, zero, B, heads, Tq, Tk, Tq_pitch, Tk_pitch, dtype, nullptr, 0, o_dev,
+                                  (int64_t)heads * 64 * Tq, (hipStream_t)stream);
+}
+
 int mi_attention_image(const float *q_dev, const float *k_dev, const float *v_dev, void *img_dev, int64_t n_img, int32_t B,
                        int32_t heads, int32_t Tq, int32_t Tk, int64_t q_batch_stride, int64_t kv_batch_stride, int32_t dtype,
                        void *stream) {

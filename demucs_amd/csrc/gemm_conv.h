@@ -33,6 +33,10 @@ enum mi_epilogue {
  *     y = act( rstd[n] * (acc - mean[n] * c1[m]) + c2[m] )                                      */
 #define MI_FLAG_LN 32
 #define MI_FLAG_IMG 64     /* LINEAR, half modes: the result goes to `yh` as a 16-bit operand image instead of `y` */
+/* LINEAR, half modes, attention projections (M = 512 n rows, O1 = 1): the result goes to `yh` ONLY, as 16-bit per-head
+ * token-major tensors  yh[row / 512][b][head = (row / 64) % 8][token (pitch yh_n)][row % 64]  -- the operands of
+ * attention_heads.hip (Q, K, V are consumed by nothing else: no float32 copy is written) */
+#define MI_FLAG_HEADS 128
 
 typedef struct mi_ktab_entry {
     int32_t off; /* element offset added to the column base: ci*chan_stride + d1*D2 + d2 */

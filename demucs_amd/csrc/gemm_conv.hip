@@ -294,6 +294,12 @@ static float *conv_sink() {
 }
 
 
+// 256 bytes of zeros in device memory (the tail of the sink): source of LDS-DMA loads that fall outside a tensor
+const void *conv_zero_page() {
+    float *p = conv_sink();
+    return p ? p + 256 : nullptr;
+}
+
 // ---------------------------------------------------------------------------------------------
 // MI_X6_VERIFY=1 (debugging aid for the split-bf16 path): every x6 launch is followed, on the same stream and with no
 // host synchronisation, by the fp32 kernel of the same layer into a scratch copy of the output and a comparison whose
@@ -389,6 +395,9 @@ int launch_conv(const mi_conv_desc &din, hipStream_t st) {
     MI_REQUIRE(!(d.flags & MI_FLAG_IMG) || (d.half && d.yh && d.epi == MI_EPI_LINEAR && d.M % 8 == 0 && d.yh_n >= (int64_t)d.B * P &&
                                             ((uintptr_t)d.yh & 15) == 0),
                "conv: MI_FLAG_IMG needs a half-precision LINEAR layer with M %% 8 == 0 and an aligned output image of >= B * P columns");
+    MI_REQUIRE(!(d.flags & MI_FLAG_HEADS) || (d.half && d.yh && d.epi == MI_EPI_LINEAR && d.M % 512 == 0 && d.O1 == 1 && d.yh_n >= d.O2 &&
+                                              ((uintptr_t)d.yh & 15) == 0 && !(d.flags & MI_FLAG_IMG)),
+               "conv: MI_FLAG_HEADS needs a half-precision LINEAR layer on tokens (O1 = 1) with M %% 512 == 0 and an aligned output");
     MI_REQUIRE(!d.xh || d.half, "conv: an operand-image input needs a half-precision layer");
     if (d.half) return launch_conv_half(d, tile, plain, st);
     static const int x6_mode = getenv("MI_X6_MODE") ? atoi(getenv("MI_X6_MODE")) : 0;   // bisecting: 1 plain only, 2 gather only

@@ -391,8 +391,9 @@ static int launch_conv_half_t(const mi_conv_desc &d, int tile, bool plain, hipSt
         return d.Mpad % 256 == 0 ? launch_half_img<HT, 4, MI_FLAG_SCALE | MI_FLAG_RES>(d, st) : launch_half_img<HT, 2, MI_FLAG_SCALE | MI_FLAG_RES>(d, st);
     }
     if (d.epi == MI_EPI_LINEAR) {
-        switch (d.flags & (MI_FLAG_GELU | MI_FLAG_SCALE | MI_FLAG_RES | MI_FLAG_LN | MI_FLAG_IMG)) {
+        switch (d.flags & (MI_FLAG_GELU | MI_FLAG_SCALE | MI_FLAG_RES | MI_FLAG_LN | MI_FLAG_IMG | MI_FLAG_HEADS)) {
             MI_LINEAR(MI_FLAG_LN | MI_FLAG_GELU | MI_FLAG_IMG);
+            MI_LINEAR(MI_FLAG_LN | MI_FLAG_HEADS);
             MI_LINEAR(0);
             MI_LINEAR(MI_FLAG_GELU);
             MI_LINEAR(MI_FLAG_RES);

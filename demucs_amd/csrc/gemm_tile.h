@@ -106,6 +106,17 @@ __device__ __forceinline__ void conv_epilogue(const mi_conv_desc &d, f32x16 (&ac
                     if (LFLAGS & MI_FLAG_GELU) v = gelu_exact(v);
                     if (LFLAGS & MI_FLAG_SCALE) v *= auxr[r];
                     if (LFLAGS & MI_FLAG_RES) v += resv[r];
+                    if (LFLAGS & MI_FLAG_HEADS) {
+                        // four consecutive channels of one head and token: one 8-byte store into that token's 128-byte row
+                        vq[r & 3] = v;
+                        if ((r & 3) == 3) {
+                            const int mo = mbase + 8 * (r >> 2);
+                            const size_t plane = ((size_t)(mo >> 9) * d.B + c.b) * 8 + ((mo >> 6) & 7);
+                            uint2 *dst = reinterpret_cast<uint2 *>(d.yh) + ((plane * d.yh_n + c.p) * 64 + (mo & 63)) / 4;
+                            if (c.valid && mo < d.M) *dst = make_uint2(pack_half2(d.half, vq[0], vq[1]), pack_half2(d.half, vq[2], vq[3]));
+                        }
+                        continue;
+                    }
                     if (LFLAGS & MI_FLAG_IMG) {
                         // four consecutive rows of a k-octet of the NEXT layer's operand: one 8-byte store into its image
                         vq[r & 3] = v;

@@ -114,6 +114,11 @@ int launch_ola_finish(float *acc, int64_t acc_len, int rows, int64_t acc_off0, c
 int launch_resample_frac(const float *x, int rows, int64_t L, const float *table, int old_sr, int new_sr, int width, float *y,
                          int64_t Lout, hipStream_t st);
 
+const void *conv_zero_page();      // gemm_conv.hip: 256 bytes of device zeros
+// attention_heads.hip: half modes, per-head token-major 16-bit operands (MI_FLAG_HEADS), LDS-DMA ring
+int launch_attention_heads(const void *q, const void *k, const void *v, const void *zero_page, int B, int heads, int Tq, int Tk, int Tq_pitch,
+                           int Tk_pitch, int dtype, void *oh, int64_t oh_n, float *o, int64_t o_bs, hipStream_t st);
+
 // post.hip: Separator normalisation, clip prevention, two-stems sums
 int post_stats_scratch_bytes();
 int launch_mono_stats(const float *wav, int channels, int64_t length, double *scratch, float *stats, hipStream_t st);

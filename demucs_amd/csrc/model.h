@@ -111,6 +111,7 @@ struct Model : WorkspacePtrs {
     int conv(const mi_conv_desc &d, hipStream_t st);
     int attn(const float *q, const float *k, const float *v, float *o, int B, int Tq, int Tk, int64_t q_bs, int64_t kv_bs,
              int64_t o_bs, hipStream_t st, bool image = false);
+    int attn_heads(const void *q, const void *k, const void *v, float *o, int B, int Tq, int Tk, hipStream_t st);
     int S = 0, SL = 0, T = 0, Lt[5] = {};   // time-branch lengths per level
     int Lp[5] = {};                         // ... and their row pitches (rounded up to 4 floats: 16-byte aligned rows)
     int64_t device_bytes = 0;

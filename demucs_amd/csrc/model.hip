@@ -128,6 +128,23 @@ int Model::attn(const float *q, const float *k, const float *v, float *o, int B,
     return r;
 }
 
+// half modes: per-head 16-bit operands [B][8][T][64] (written by the projections' MI_FLAG_HEADS epilogue); the output is always
+// out_proj's operand image
+int Model::attn_heads(const void *q, const void *k, const void *v, float *o, int B, int Tq, int Tk, hipStream_t st) {
+    const int64_t oh_n = (int64_t)B * Tq;
+    const void *zero = conv_zero_page();
+    MI_REQUIRE(zero, "attention: could not allocate the zero page");
+    if (!prof.on) return launch_attention_heads(q, k, v, zero, B, 8, Tq, Tk, Tq, Tk, cfg.dtype, o, oh_n, nullptr, 0, st);
+    const int cls = 100;
+    Profiler::Pending p{cls, prof.get(), prof.get(), 4.0 * B * 8 * (double)Tq * Tk * 64.0, 2.0 * B * 512.0 * (2.0 * Tq + 2.0 * Tk)};
+    MI_HIP(hipEventRecord(p.a, st));
+    const int r = launch_attention_heads(q, k, v, zero, B, 8, Tq, Tk, Tq, Tk, cfg.dtype, o, oh_n, nullptr, 0, st);
+    MI_HIP(hipEventRecord(p.b, st));
+    prof.pending.push_back(p);
+    snprintf(prof.rows[cls].name, sizeof(prof.rows[cls].name), "attention_heads%s_kernel", cfg.dtype == MI_DTYPE_BF16 ? "_bf16" : "_f16");
+    return r;
+}
+
 // ------------------------------------------------------------------------------------------------
 // weight lookup and packing
 // ------------------------------------------------------------------------------------------------
@@ -696,24 +713,36 @@ int Model::run_tr_layer(int br, int k, int B, const float *x, const float2 *xsta
     // 16-bit operand image, in place of the float32 tensor, and consumed by the LDS-DMA main loop of gemm_half.hip
     static const bool no_img = getenv("MI_NO_FFN_IMAGE") != nullptr;
     const bool img = cfg.dtype != MI_DTYPE_F32 && !no_img;
+    // half modes: Q, K, V feed nothing but the attention kernel, so the projections write them ONLY as 16-bit per-head token-major
+    // tensors (MI_FLAG_HEADS, no float32 copy) and attention_heads.hip moves K / V tiles global -> LDS by DMA
+    static const bool no_heads = getenv("MI_NO_QKV_HEADS") != nullptr;
+    const bool heads = img && !no_heads;
+    unsigned short *qh = reinterpret_cast<unsigned short *>(qkv);
+    const size_t plane_q = (size_t)B * 512 * Tq, plane_k = (size_t)B * 512 * Tk;        // 16-bit elements of one of Q / K / V
     if (!cross) {
         mi_conv_desc d = base_desc(l.qkv_proj, tr_ktab512[br], x, (int64_t)512 * Tq, gq);
         d.plain = 1; d.epi = MI_EPI_LINEAR; d.flags = MI_FLAG_LN; d.scale = l.qkv_c1; d.pro_stats = (const float *)xstat;
         d.y = qkv; d.y_bstride = (int64_t)1536 * Tq; d.y_cstride = Tq;
+        if (heads) { d.flags |= MI_FLAG_HEADS; d.yh = qh; d.yh_n = Tq; }
         MI_TRY(conv(d, st));
-        MI_TRY(attn(qkv, qkv + (size_t)512 * Tq, qkv + (size_t)1024 * Tq, att, B, Tq, Tq, (int64_t)1536 * Tq, (int64_t)1536 * Tq,
-                    (int64_t)512 * Tq, st, img));
+        if (heads) MI_TRY(attn_heads(qh, qh + plane_q, qh + 2 * plane_q, att, B, Tq, Tq, st));
+        else MI_TRY(attn(qkv, qkv + (size_t)512 * Tq, qkv + (size_t)1024 * Tq, att, B, Tq, Tq, (int64_t)1536 * Tq, (int64_t)1536 * Tq,
+                         (int64_t)512 * Tq, st, img));
     } else {
         mi_conv_desc d = base_desc(l.q_proj, tr_ktab512[br], x, (int64_t)512 * Tq, gq);
         d.plain = 1; d.epi = MI_EPI_LINEAR; d.flags = MI_FLAG_LN; d.scale = l.q_c1; d.pro_stats = (const float *)xstat;
         d.y = qkv; d.y_bstride = (int64_t)512 * Tq; d.y_cstride = Tq;
+        if (heads) { d.flags |= MI_FLAG_HEADS; d.yh = qh; d.yh_n = Tq; }
         MI_TRY(conv(d, st));
         float *kv = qkv + (size_t)B * 512 * Tq;
+        unsigned short *kvh = qh + plane_q;
         mi_conv_desc e = base_desc(l.kv_proj, tr_ktab512[1 - br], other, (int64_t)512 * Tk, gk);
         e.plain = 1; e.epi = MI_EPI_LINEAR; e.flags = MI_FLAG_LN; e.scale = l.kv_c1; e.pro_stats = (const float *)ostat;
         e.y = kv; e.y_bstride = (int64_t)1024 * Tk; e.y_cstride = Tk;
+        if (heads) { e.flags |= MI_FLAG_HEADS; e.yh = kvh; e.yh_n = Tk; }
         MI_TRY(conv(e, st));
-        MI_TRY(attn(qkv, kv, kv + (size_t)512 * Tk, att, B, Tq, Tk, (int64_t)512 * Tq, (int64_t)1024 * Tk, (int64_t)512 * Tq, st, img));
+        if (heads) MI_TRY(attn_heads(qh, kvh, kvh + plane_k, att, B, Tq, Tk, st));
+        else MI_TRY(attn(qkv, kv, kv + (size_t)512 * Tk, att, B, Tq, Tk, (int64_t)512 * Tq, (int64_t)1024 * Tk, (int64_t)512 * Tq, st, img));
     }
     {   // x1 = x + gamma_1 * (out_proj(att) + b)
         mi_conv_desc d = base_desc(l.out_proj, tr_ktab512[br], att, (int64_t)512 * Tq, gq);

@@ -208,6 +208,13 @@ int mi_attention(const float *q_dev, const float *k_dev, const float *v_dev, flo
                  int32_t Tq, int32_t Tk, int64_t q_batch_stride, int64_t kv_batch_stride, int64_t o_batch_stride,
                  int32_t dtype, void *stream);
 
+/* mi_attention_heads: the attention core of the half modes on the operands the projections really write in those modes:
+ *   q / k / v_dev are 16-bit (bf16 / fp16 by `dtype`) per-head token-major tensors [B][heads][T pitch][64] (what the
+ *   MI_FLAG_HEADS epilogue of the in-projection produces; K / V tiles reach LDS by DMA); o_dev float32 (B, heads * 64, Tq)
+ *   = softmax(q k^T / 8) v per head (demucs/transformer.py:339-377,466-512). */
+int mi_attention_heads(const void *q_dev, const void *k_dev, const void *v_dev, float *o_dev, int32_t B, int32_t heads, int32_t Tq, int32_t Tk,
+                       int32_t Tq_pitch, int32_t Tk_pitch, int32_t dtype, void *stream);
+
 /* mi_attention in a half mode with the result written as the 16-bit operand image of the projection that consumes it
  *   (out_proj, demucs/transformer.py:418-419 inside nn.MultiheadAttention): img_dev[(heads * 64) / 8][n_img][8] bf16 / fp16,
  *   column b * Tq + query, n_img >= B * Tq; element values are the float32 results of mi_attention rounded to nearest even.

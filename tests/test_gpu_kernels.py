@@ -400,6 +400,39 @@ def test_attention_matches_softmax(lib, dtype):
         assert torch.equal(img, want_img)
 
 
+@pytest.mark.parametrize("dtype", [1, 2], ids=["bf16", "f16"])
+@pytest.mark.parametrize("Tq,Tk,pitch,spike", [(200, 320, 64, True), (200, 320, 0, False), (333, 97, 8, False), (64, 2688, 0, False)])
+def test_attention_heads_matches_softmax(lib, dtype, Tq, Tk, pitch, spike):
+    """`mi_attention_heads` (attention_heads.hip): the half modes' attention on the 16-bit per-head token-major operands the
+    in-projections write (K / V tiles by LDS-DMA, swizzled LDS image, transposed V reads).  The float64 softmax of the SAME
+    rounded operands is the reference, so only the probabilities' rounding (2^-9 / 2^-12 relative) and float32 accumulation
+    remain: tight bounds on un-spiked data; the spiked case (|score| ~ 30) gets the bound of test_attention_matches_softmax.
+    Ragged Tq / Tk (last tile masked, rows past Tk read from the zero page), row pitches above the token counts, a long key axis."""
+    B, H = 2, 8
+    hdt = torch.bfloat16 if dtype == 1 else torch.float16
+    q, k, v = rnd(B, H, Tq, 64, seed=140), rnd(B, H, Tk, 64, seed=141), rnd(B, H, Tk, 64, seed=142)
+    if spike:
+        k[:, :, 170] *= 6.0
+    qh, kh, vh = q.to(hdt), k.to(hdt), v.to(hdt)
+    Q, K, V = qh.double(), kh.double(), vh.double()
+    want = (torch.softmax(Q @ K.transpose(-1, -2) / 8.0, dim=-1) @ V).transpose(2, 3).reshape(B, 512, Tq)
+    Tqp, Tkp = Tq + pitch, Tk + pitch
+
+    def padded(t, Tp):           # rows past T hold NaNs: they must never reach a product
+        out = torch.full((B, H, Tp, 64), float("nan"), dtype=hdt)
+        out[:, :, :t.shape[2]] = t
+        return out.cuda().contiguous()
+    qd, kd, vd = padded(qh, Tqp), padded(kh, Tkp), padded(vh, Tkp)
+    o = torch.empty(B, 512, Tq, device="cuda")
+    _lib.check(lib.mi_attention_heads(qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), o.data_ptr(), B, H, Tq, Tk, Tqp, Tkp, dtype, stream()),
+               "mi_attention_heads")
+    torch.cuda.synchronize()
+    err = maxerr(o, want)
+    print(f"attention_heads dtype {dtype} Tq {Tq} Tk {Tk}: max-abs vs float64 softmax of the rounded operands {err:.2e}")
+    assert bool(torch.isfinite(o).all())
+    assert err < ([0, 6e-2, 8e-3][dtype] if spike else [0, 6e-3, 8e-4][dtype])
+
+
 def test_layernorm_channel_first(lib):
     B, Cn, Tn = 2, 512, 333
     x = rnd(B, Cn, Tn, seed=50) * 3 + 40.0          # large mean: checks the shifted one-pass variance
