@@ -50,13 +50,33 @@ __device__ __forceinline__ f32x16 hmfma(const uint4 a, const uint4 b, const f32x
     else
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
+// value of the lane 32 away combined with this lane's: v_permlane32_swap (VALU) instead of the ds_bpermute that __shfl_xor(x, 32)
+// becomes (an LDS round trip and an lgkmcnt(0) wait in the middle of the softmax)
+__device__ __forceinline__ float other_half(float x) {
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    const u2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return (threadIdx.x & 32) ? __uint_as_float(r[0]) : __uint_as_float(r[1]);
+}
+// max of three without the canonicalising v_max hipcc puts in front of fmaxf on matrix-pipe results (the softmax is bound by
+// VALU issue slots: ~4.6 cycles of the SIMD per wave instruction, counters in tools/micro/README.md)
+__device__ __forceinline__ float max3(float a, float b, float cc) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(cc));
+    return r;
+}
+// max(a, b) over this lane and the lane 32 away
+__device__ __forceinline__ float other_half_max(float a, float b) {
+    float m;
+    asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(a), "v"(b));
+    return other_half(m);
+}
 __device__ __forceinline__ int swz(int key) { return (((key >> 1) & 1) << 2) | ((key >> 2) & 3); }
 }  // namespace
 
 template <int HT>
 __global__ __launch_bounds__(256, 1) void attention_heads_kernel(const uint4 *__restrict__ qimg, const uint4 *__restrict__ kimg,
-                                                                 const uint4 *__restrict__ vimg, const uint4 *__restrict__ zero, int Tq,
-                                                                 int Tk, int Tqp, int Tkp, void *__restrict__ oh, int64_t oh_n,
+                                                                 const uint4 *__restrict__ vimg, const uint4 *__restrict__ zero, int planes,
+                                                                 int heads, int Tq, int Tk, int Tqp, int Tkp, void *__restrict__ oh, int64_t oh_n,
                                                                  float *__restrict__ o, int64_t o_bs) {
     __shared__ __attribute__((aligned(16))) uint4 smem[3 * ASTAGE];
 #ifdef MI_AGPR_ACC          // `make MFMA_FORM=agpr`: accumulators in AGPRs (see gemm_x6.hip); the default build keeps this kernel in the
@@ -68,9 +88,15 @@ __global__ __launch_bounds__(256, 1) void attention_heads_kernel(const uint4 *__
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
-    const int head = blockIdx.y, b = blockIdx.z, heads = gridDim.y;
-    const size_t plane = (size_t)b * heads + head;
-    const int q0 = blockIdx.x * 256 + wave * 64;
+    // XCD-aware order (workgroups id, id + 8, ... share one of the 8 L2s): all query blocks of one (item, head) plane run on the
+    // SAME XCD, so its K / V (688 KiB at 2 688 keys) is fetched into one L2 instead of eight
+    const int nqb = (Tq + 255) / 256;
+    const int xj = blockIdx.x >> 3;
+    const int pl = (xj / nqb) * 8 + (blockIdx.x & 7);
+    if (pl >= planes) return;                                      // grid padding (whole workgroup, before any barrier)
+    const int head = pl % heads, b = pl / heads;
+    const size_t plane = (size_t)pl;
+    const int q0 = (xj % nqb) * 256 + wave * 64;
     const bool active = q0 < Tq;                                   // wave-uniform: a wave past the last query only moves tiles
     const uint4 *kp = kimg + plane * (size_t)Tkp * AROW, *vp = vimg + plane * (size_t)Tkp * AROW;
     const int nt = (Tk + AKT - 1) / AKT;
@@ -79,18 +105,29 @@ __global__ __launch_bounds__(256, 1) void attention_heads_kernel(const uint4 *__
     //      lane -> (key 8 j + (lane >> 3), slot lane & 7) holds source chunk slot ^ f(key)
     const int dkey = 16 * wave + (lane >> 3);
     const int dch0 = (lane & 7) ^ swz(dkey), dch1 = (lane & 7) ^ swz(dkey + 8);
+    // full tiles: wave-uniform tile base (scalar arithmetic) + two constant per-lane byte offsets -- no VALU slot per tile; the
+    // ragged last tile (rows past Tk come from the zero page) takes per-lane addresses
+    const unsigned doff0 = (unsigned)((dkey * AROW + dch0) * 16), doff1 = (unsigned)(((dkey + 8) * AROW + dch1) * 16);
 #define MI_ATT_TILE(t, stage)                                                                                          \
     do {                                                                                                               \
         uint4 *sk = smem + (stage) * ASTAGE + 16 * wave * AROW, *sv = sk + AKT * AROW;                                 \
-        const int k0_ = (t) * AKT + dkey;                                                                              \
-        const uint4 *g0 = (k0_ < Tk) ? kp + (size_t)k0_ * AROW + dch0 : zero;                                          \
-        const uint4 *g1 = (k0_ + 8 < Tk) ? kp + (size_t)(k0_ + 8) * AROW + dch1 : zero;                                \
-        const uint4 *h0 = (k0_ < Tk) ? vp + (size_t)k0_ * AROW + dch0 : zero;                                          \
-        const uint4 *h1 = (k0_ + 8 < Tk) ? vp + (size_t)(k0_ + 8) * AROW + dch1 : zero;                                \
-        __builtin_amdgcn_global_load_lds((agvoid_t *)g0, (alvoid_t *)sk, 16, 0, 0);                                    \
-        __builtin_amdgcn_global_load_lds((agvoid_t *)g1, (alvoid_t *)(sk + 8 * AROW), 16, 0, 0);                       \
-        __builtin_amdgcn_global_load_lds((agvoid_t *)h0, (alvoid_t *)sv, 16, 0, 0);                                    \
-        __builtin_amdgcn_global_load_lds((agvoid_t *)h1, (alvoid_t *)(sv + 8 * AROW), 16, 0, 0);                       \
+        if (((t) + 1) * AKT <= Tk) {                                                                                   \
+            const uint4 *kt_ = kp + (size_t)(t) * AKT * AROW, *vt_ = vp + (size_t)(t) * AKT * AROW;                    \
+            lds_dma16_s(kt_, doff0, sk);                                                                               \
+            lds_dma16_s(kt_, doff1, sk + 8 * AROW);                                                                    \
+            lds_dma16_s(vt_, doff0, sv);                                                                               \
+            lds_dma16_s(vt_, doff1, sv + 8 * AROW);                                                                    \
+        } else {                                                                                                       \
+            const int k0_ = (t) * AKT + dkey;                                                                          \
+            const uint4 *g0 = (k0_ < Tk) ? kp + (size_t)k0_ * AROW + dch0 : zero;                                      \
+            const uint4 *g1 = (k0_ + 8 < Tk) ? kp + (size_t)(k0_ + 8) * AROW + dch1 : zero;                            \
+            const uint4 *h0 = (k0_ < Tk) ? vp + (size_t)k0_ * AROW + dch0 : zero;                                      \
+            const uint4 *h1 = (k0_ + 8 < Tk) ? vp + (size_t)(k0_ + 8) * AROW + dch1 : zero;                            \
+            lds_dma16(g0, sk);                                                                                         \
+            lds_dma16(g1, sk + 8 * AROW);                                                                              \
+            lds_dma16(h0, sv);                                                                                         \
+            lds_dma16(h1, sv + 8 * AROW);                                                                              \
+        }                                                                                                              \
     } while (0)
 
     MI_ATT_TILE(0, 0);
@@ -105,9 +142,14 @@ __global__ __launch_bounds__(256, 1) void attention_heads_kernel(const uint4 *__
 #pragma unroll
         for (int s = 0; s < 4; ++s) qf[qb][s] = qrow[2 * s + lh];
     }
-    // everything issued so far (two tiles, the Q rows) has landed before the loop: inside it only DMA is ever in flight, so
-    // the compiler has no register load to wait for and the counted waits below are the only ones
+    // everything issued so far (two tiles, the Q rows) has landed before the loop: inside it only DMA is ever in flight.  The
+    // empty asm statements USE the Q registers, so hipcc places its own wait for those loads here; without them it carries
+    // "Q may still be in flight" into the loop and its vmcnt(7) ... vmcnt(0) in front of the first products drain the ring
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(qf[qb][s].x), "+v"(qf[qb][s].y), "+v"(qf[qb][s].z), "+v"(qf[qb][s].w));
 
     f32x16 oacc[2][2];
 #pragma unroll
@@ -136,95 +178,118 @@ __global__ __launch_bounds__(256, 1) void attention_heads_kernel(const uint4 *__
             voff[e][dt] = key * 128 + (((4 * dt + 2 * vg + (vpp >> 1)) ^ swz(key)) * 16) + 8 * (vpp & 1);
         }
 
+    // S^T of one 32-key block for both query blocks: K fragments (shared), 8 products.  Keys past Tk (ragged last tile only,
+    // wave-uniform test) enter as -inf through the accumulator's initial value, so no select touches the scores afterwards.
+    auto score = [&](const uint4 *Ks, int sub, int kb, f32x16(&sc)[2]) {
+        uint4 kf[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) kf[s] = Ks[32 * sub * AROW + koff[s]];
+        if (kb + 32 > Tk) {          // ragged last tile: a real branch (the asm keeps hipcc from turning it into 32 selects per call)
+            asm volatile("; ragged key block");
+            f32x16 init;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) init[r] = (kb + (r & 3) + 8 * (r >> 2) + 4 * lh >= Tk) ? -INFINITY : 0.f;
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                sc[qb] = hmfma<HT>(kf[0], qf[qb][0], init);
+#pragma unroll
+                for (int s = 1; s < 4; ++s) sc[qb] = hmfma<HT>(kf[s], qf[qb][s], sc[qb]);
+            }
+        } else {
+            f32x16 zero16;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                sc[qb] = hmfma<HT>(kf[0], qf[qb][0], zero16);
+#pragma unroll
+                for (int s = 1; s < 4; ++s) sc[qb] = hmfma<HT>(kf[s], qf[qb][s], sc[qb]);
+            }
+        }
+    };
+    // online softmax of one 32-key block's scores and the second product, both query blocks
+    auto finish = [&](const char *Vs, int sub, f32x16(&sc)[2]) {
+        // V fragments (A operand): element j of lane half lh is key 16 tt + 8 (j >> 2) + 4 lh + (j & 3), the key order of the
+        // accumulator rows that become the B operand
+        uint4 vf[2][2];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                const char *base = Vs + (32 * sub + 16 * tt) * 128;
+                const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s *)(base + voff[0][dt]));
+                const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s *)(base + voff[1][dt]));
+                const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+                vf[dt][tt] = make_uint4(l2.x, l2.y, h2.x, h2.y);
+            }
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            // register r of lane (li, lh) is key (r & 3) + 8 (r >> 2) + 4 lh of the block, query li
+            float mloc = max3(max3(max3(sc[qb][0], sc[qb][1], sc[qb][2]), sc[qb][3], sc[qb][4]), max3(sc[qb][5], sc[qb][6], sc[qb][7]),
+                              max3(max3(sc[qb][8], sc[qb][9], sc[qb][10]), sc[qb][11], sc[qb][12]));
+            mloc = max3(mloc, max3(sc[qb][13], sc[qb][14], sc[qb][15]), other_half_max(mloc, max3(sc[qb][13], sc[qb][14], sc[qb][15])));
+            const float mnew = fmaxf(mrun[qb], mloc);
+            if (__any(mnew != mrun[qb])) {
+                const float alpha = __builtin_amdgcn_exp2f((mrun[qb] - mnew) * c);
+                lrun[qb] *= alpha;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { oacc[qb][0][r] *= alpha; oacc[qb][1][r] *= alpha; }
+                mrun[qb] = mnew;
+            }
+            // p = 2^(s c - m c): the multiply-adds and the row sum as PACKED float32 operations (two values per VALU slot)
+            const v2f cc2 = splat2(c), nm2 = splat2(-mnew * c);
+            v2f ps2 = splat2(0.f);
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const v2f a = fma2((v2f){sc[qb][r], sc[qb][r + 1]}, cc2, nm2);
+                const v2f pp = {__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)};
+                sc[qb][r] = pp.x; sc[qb][r + 1] = pp.y;
+                ps2 += pp;
+            }
+            lrun[qb] += ps2.x + ps2.y;
+            uint4 pb[2];
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+                pb[tt] = make_uint4(hpack2<HT>(sc[qb][8 * tt], sc[qb][8 * tt + 1]), hpack2<HT>(sc[qb][8 * tt + 2], sc[qb][8 * tt + 3]),
+                                    hpack2<HT>(sc[qb][8 * tt + 4], sc[qb][8 * tt + 5]), hpack2<HT>(sc[qb][8 * tt + 6], sc[qb][8 * tt + 7]));
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                oacc[qb][0] = hmfma<HT>(vf[0][tt], pb[tt], oacc[qb][0]);
+                oacc[qb][1] = hmfma<HT>(vf[1][tt], pb[tt], oacc[qb][1]);
+            }
+        }
+    };
+
+    // Software pipeline over 32-key blocks: the scores of block i + 1 are issued to the matrix pipe BEFORE the softmax of block
+    // i runs on the VALU (two named accumulator sets), so one wave keeps both pipes busy; the only barrier of an iteration is
+    // at its end, behind a full drain of the DMA queue: tile t + 2, issued at the top of iteration t, is first read in
+    // iteration t + 1 (block 0 of tile t + 2 is scored there), a whole tile time after its issue.
+    __builtin_amdgcn_s_barrier();                 // tiles 0 and 1 have landed for every wave (each waited for its own parts above)
+    f32x16 sA[2], sB[2];
+    if (active) score(smem, 0, 0, sA);
     int stage = 0;
     for (int t = 0; t < nt; ++t) {
-        // tile t has landed once all but this wave's newest tile (4 instructions) are done -- for every wave after the barrier
-        if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        // stage (t + 2) % 3 was last read in the previous iteration, which every wave has finished
+        const int nstage = stage == 2 ? 0 : stage + 1;
+        // stage (t + 2) % 3 held tile t - 1: last read in iteration t - 1, which every wave has left through its barrier
         if (t + 2 < nt) MI_ATT_TILE(t + 2, stage == 0 ? 2 : stage - 1);
         if (active) {
             const uint4 *Ks = smem + stage * ASTAGE;
             const char *Vs = reinterpret_cast<const char *>(Ks + AKT * AROW);
-#pragma unroll
-            for (int sub = 0; sub < 2; ++sub) {
-                uint4 kf[4];
-#pragma unroll
-                for (int s = 0; s < 4; ++s) kf[s] = Ks[32 * sub * AROW + koff[s]];
-                f32x16 sacc[2];
-#pragma unroll
-                for (int qb = 0; qb < 2; ++qb) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) sacc[qb][r] = 0.f;
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) sacc[qb] = hmfma<HT>(kf[s], qf[qb][s], sacc[qb]);
-                }
-                // V fragments (A operand of the second product): element j of lane half lh is key 16 t + 8 (j >> 2) + 4 lh + (j & 3),
-                // the key order of the accumulator rows that become the B operand
-                uint4 vf[2][2];
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-                    for (int tt = 0; tt < 2; ++tt) {
-                        const char *base = Vs + (32 * sub + 16 * tt) * 128;
-                        const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s *)(base + voff[0][dt]));
-                        const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s *)(base + voff[1][dt]));
-                        const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
-                        vf[dt][tt] = make_uint4(l2.x, l2.y, h2.x, h2.y);
-                    }
-                const int kb = t * AKT + 32 * sub;
-#pragma unroll
-                for (int qb = 0; qb < 2; ++qb) {
-                    // register r of lane (li, lh) is key kb + (r & 3) + 8 (r >> 2) + 4 lh, query li
-                    if (kb + 32 > Tk) {              // ragged last tile only (wave-uniform): mask keys past Tk
-#pragma unroll
-                        for (int r = 0; r < 16; ++r)
-                            if (kb + (r & 3) + 8 * (r >> 2) + 4 * lh >= Tk) sacc[qb][r] = -INFINITY;
-                    }
-                    float m0 = fmaxf(fmaxf(sacc[qb][0], sacc[qb][1]), sacc[qb][2]), m1 = fmaxf(fmaxf(sacc[qb][3], sacc[qb][4]), sacc[qb][5]);
-                    float m2 = fmaxf(fmaxf(sacc[qb][6], sacc[qb][7]), sacc[qb][8]), m3 = fmaxf(fmaxf(sacc[qb][9], sacc[qb][10]), sacc[qb][11]);
-                    float m4 = fmaxf(fmaxf(sacc[qb][12], sacc[qb][13]), sacc[qb][14]);
-                    float mloc = fmaxf(fmaxf(fmaxf(m0, m1), fmaxf(m2, m3)), fmaxf(m4, sacc[qb][15]));
-                    mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
-                    const float mnew = fmaxf(mrun[qb], mloc);
-                    if (__any(mnew != mrun[qb])) {
-                        const float alpha = __builtin_amdgcn_exp2f((mrun[qb] - mnew) * c);
-                        lrun[qb] *= alpha;
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) { oacc[qb][0][r] *= alpha; oacc[qb][1][r] *= alpha; }
-                        mrun[qb] = mnew;
-                    }
-                    const float nm = -mnew * c;
-                    float psum = 0.f;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float p = __builtin_amdgcn_exp2f(fmaf(sacc[qb][r], c, nm));
-                        sacc[qb][r] = p;
-                        psum += p;
-                    }
-                    lrun[qb] += psum;
-                    uint4 pb[2];
-#pragma unroll
-                    for (int tt = 0; tt < 2; ++tt)
-                        pb[tt] = make_uint4(hpack2<HT>(sacc[qb][8 * tt], sacc[qb][8 * tt + 1]), hpack2<HT>(sacc[qb][8 * tt + 2], sacc[qb][8 * tt + 3]),
-                                            hpack2<HT>(sacc[qb][8 * tt + 4], sacc[qb][8 * tt + 5]), hpack2<HT>(sacc[qb][8 * tt + 6], sacc[qb][8 * tt + 7]));
-#pragma unroll
-                    for (int tt = 0; tt < 2; ++tt) {
-                        oacc[qb][0] = hmfma<HT>(vf[0][tt], pb[tt], oacc[qb][0]);
-                        oacc[qb][1] = hmfma<HT>(vf[1][tt], pb[tt], oacc[qb][1]);
-                    }
-                }
-            }
+            score(Ks, 1, t * AKT + 32, sB);
+            finish(Vs, 0, sA);
+            if (t + 1 < nt) score(smem + nstage * ASTAGE, 0, (t + 1) * AKT, sA);
+            finish(Vs, 1, sB);
         }
-        stage = stage == 2 ? 0 : stage + 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        stage = nstage;
     }
 #undef MI_ATT_TILE
     if (!active) return;
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
         const int qi = q0 + 32 * qb + li;
-        const float ltot = lrun[qb] + __shfl_xor(lrun[qb], 32);
+        const float ltot = lrun[qb] + other_half(lrun[qb]);
         const float inv = 1.0f / ltot;
         if (qi >= Tq) continue;
         if (oh) {
@@ -261,12 +326,13 @@ int launch_attention_heads(const void *q, const void *k, const void *v, const vo
     MI_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)zero_page) & 15) == 0, "attention: operand tensors must be 16-byte aligned");
     MI_REQUIRE((oh != nullptr) != (o != nullptr), "attention: exactly one output form");
     MI_REQUIRE(!oh || (oh_n >= (int64_t)B * Tq && ((uintptr_t)oh & 15) == 0), "attention: output image too small or misaligned");
-    const dim3 grid(ceil_div(Tq, 256), heads, B);
+    const int planes = B * heads;
+    const dim3 grid((unsigned)(ceil_div(Tq, 256) * ((planes + 7) / 8) * 8));
     const uint4 *q4 = (const uint4 *)q, *k4 = (const uint4 *)k, *v4 = (const uint4 *)v, *z4 = (const uint4 *)zero_page;
     if (dtype == MI_DTYPE_BF16)
-        hipLaunchKernelGGL(attention_heads_kernel<MI_DTYPE_BF16>, grid, dim3(256), 0, st, q4, k4, v4, z4, Tq, Tk, Tq_pitch, Tk_pitch, oh, oh_n, o, o_bs);
+        hipLaunchKernelGGL(attention_heads_kernel<MI_DTYPE_BF16>, grid, dim3(256), 0, st, q4, k4, v4, z4, planes, heads, Tq, Tk, Tq_pitch, Tk_pitch, oh, oh_n, o, o_bs);
     else
-        hipLaunchKernelGGL(attention_heads_kernel<MI_DTYPE_F16>, grid, dim3(256), 0, st, q4, k4, v4, z4, Tq, Tk, Tq_pitch, Tk_pitch, oh, oh_n, o, o_bs);
+        hipLaunchKernelGGL(attention_heads_kernel<MI_DTYPE_F16>, grid, dim3(256), 0, st, q4, k4, v4, z4, planes, heads, Tq, Tk, Tq_pitch, Tk_pitch, oh, oh_n, o, o_bs);
     MI_CHECK_LAUNCH();
     return MI_OK;
 }

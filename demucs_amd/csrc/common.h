@@ -80,6 +80,25 @@ __device__ __forceinline__ unsigned pack_half2(int dtype, float a, float b) {
     return __builtin_bit_cast(unsigned, h);
 }
 
+// One LDS-DMA wave instruction (global_load_lds_dwordx4: lane l's 16 bytes at `g` land at lds_wave_base + 16 l) issued from
+// inline asm.  hipcc tracks the builtin form as a pending LDS write and puts `s_waitcnt vmcnt(0)` in front of the next
+// ds_read of the same array -- which drains a multi-stage ring right after its prefetch has been issued (found in the ISA of
+// conv_gemm_half_img_kernel and attention_heads_kernel).  The asm form is invisible to that pass: ordering is then ONLY the
+// kernel's own counted `s_waitcnt vmcnt(N)` + s_barrier (vmcnt counts these like any load).  lds_wave_base must be wave-uniform.
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+__device__ __forceinline__ void lds_dma16(const void *g, void *lds_wave_base) {
+    const unsigned l = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)lds_wave_base;
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(l) : "memory", "m0");
+}
+// the same with a wave-uniform 64-bit base in SGPRs and a 32-bit per-lane byte offset: a loop that walks a tensor advances the
+// base with scalar instructions and spends no VALU slot on addresses
+__device__ __forceinline__ void lds_dma16_s(const void *sbase, unsigned voff, void *lds_wave_base) {
+    const unsigned l = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)lds_wave_base;
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(l) : "memory", "m0");
+}
+#pragma clang diagnostic pop
+
 // packed fp32 math: v_pk_fma_f32 issues two IEEE fmas per lane per instruction (same results as two fmaf)
 typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }

@@ -289,11 +289,11 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_half_img_kernel(const mi_con
     do {                                                                                                            \
         uint4 *sa = smem + (stage) * SW + 64 * (wave * NA), *sb = smem + (stage) * SW + A_W + wave * BN;             \
         _Pragma("unroll") for (int j = 0; j < NA; ++j)                                                               \
-            __builtin_amdgcn_global_load_lds((hgvoid_t *)(asrc[j] + (size_t)(kt) * a_step), (hlvoid_t *)(sa + 64 * j), 16, 0, 0); \
+            lds_dma16(asrc[j] + (size_t)(kt) * a_step, sa + 64 * j);                                                 \
         const bool kin = ((kt) * 4 + wave) * 8 < d.K;                                                               \
         const uint4 *g = b0 + (size_t)(kt) * b_step;                                                                \
-        __builtin_amdgcn_global_load_lds((hgvoid_t *)((kin && c0) ? g : zero), (hlvoid_t *)sb, 16, 0, 0);            \
-        __builtin_amdgcn_global_load_lds((hgvoid_t *)((kin && c1) ? g + 64 : zero), (hlvoid_t *)(sb + 64), 16, 0, 0); \
+        lds_dma16((kin && c0) ? g : zero, sb);                                                                      \
+        lds_dma16((kin && c1) ? g + 64 : zero, sb + 64);                                                            \
     } while (0)
 
     f32x16 acc[TM][TN];

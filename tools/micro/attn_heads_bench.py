@@ -1,11 +1,11 @@
 """Microbenchmark of attention_heads.hip on the transformer's shapes (31 segments x 8 heads; Tq / Tk = 2688 / 1344)."""
 import ctypes as C
+import os
 import sys
-import time
 
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from demucs_amd import _lib
 
 lib = _lib.load()
