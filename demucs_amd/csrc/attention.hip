@@ -21,13 +21,19 @@ constexpr int VLD = KT + 1;  // V tile row stride (A-operand reads walk rows: od
 
 __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict__ q, const float *__restrict__ k,
                                                         const float *__restrict__ v, float *__restrict__ o, int Tq, int Tk,
-                                                        int64_t q_bs, int64_t kv_bs, int64_t o_bs) {
+                                                        int64_t q_bs, int64_t kv_bs, int64_t o_bs, int planes, int heads) {
     __shared__ float Ks[HD][KT];
     __shared__ float Vs[HD][VLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
-    const int head = blockIdx.y, b = blockIdx.z;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    // XCD-aware order (workgroups id, id + 8, ... share one of the 8 L2s): all query blocks of one (item, head) plane run on the
+    // SAME XCD, so that plane's K / V (1.4 MB at 2 688 keys) is fetched into one L2 instead of eight
+    const int nqb = (Tq + 127) / 128;
+    const int xj = blockIdx.x >> 3;
+    const int pl = (xj / nqb) * 8 + (blockIdx.x & 7);
+    if (pl >= planes) return;                  // grid padding (whole workgroup, before any barrier)
+    const int head = pl % heads, b = pl / heads;
+    const int q0 = (xj % nqb) * 128 + wave * 32;
     const float *qp = q + (size_t)b * q_bs + (size_t)head * HD * Tq;
     const float *kp = k + (size_t)b * kv_bs + (size_t)head * HD * Tk;
     const float *vp = v + (size_t)b * kv_bs + (size_t)head * HD * Tk;
@@ -162,7 +168,9 @@ int launch_attention(const float *q, const float *k, const float *v, float *o, i
     MI_REQUIRE(((uintptr_t)k & 15) == 0 && ((uintptr_t)v & 15) == 0 && kv_bs % 4 == 0, "attention: k/v must be 16-byte aligned");
     MI_REQUIRE(dtype == MI_DTYPE_F32 || dtype == MI_DTYPE_BF16 || dtype == MI_DTYPE_F16, "attention: dtype %d", dtype);
     if (dtype != MI_DTYPE_F32) return launch_attention_half(q, k, v, o, B, heads, Tq, Tk, q_bs, kv_bs, o_bs, dtype, st, oh, oh_n);
-    hipLaunchKernelGGL(attention_kernel, dim3(ceil_div(Tq, 128), heads, B), dim3(256), 0, st, q, k, v, o, Tq, Tk, q_bs, kv_bs, o_bs);
+    const int planes = B * heads;
+    hipLaunchKernelGGL(attention_kernel, dim3((unsigned)(ceil_div(Tq, 128) * ((planes + 7) / 8) * 8)), dim3(256), 0, st, q, k, v, o, Tq, Tk, q_bs,
+                       kv_bs, o_bs, planes, heads);
     MI_CHECK_LAUNCH();
     return MI_OK;
 }

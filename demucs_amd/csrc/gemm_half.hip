@@ -336,6 +336,118 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_half_img_kernel(const mi_con
     conv_epilogue<TM, TN, MI_EPI_LINEAR, LFLAGS>(d, acc, m0, n0, wm, wn, N, P, o2v);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same layer on a 256 x 256 tile with EIGHT waves (2 x 4, 128 x 64 outputs each) and a FOUR-stage ring: at 256 x 128 a K step
+// moves 24 KiB global -> LDS for 2.1 MFLOP, which at the matrix pipe's rate is ~48 bytes per cycle and CU -- more than the
+// L2 -> LDS path delivers (~33, MI355X_MICROARCH.md "Indexed rows") and the SQ counters show the waves parked on vmcnt /
+// barrier 55 % of their cycles.  256 x 256 needs 32 KiB per K step for twice the work (32 B per cycle and CU), keeps three
+// K steps in flight behind a counted vmcnt, and issues its DMA with a wave-uniform base (no VALU slot on addresses).  One
+// workgroup of 512 threads per CU (128 KiB of LDS), two waves per SIMD.
+template <int HT, int LFLAGS>
+__global__ __launch_bounds__(512, 1) void conv_gemm_half_img256_kernel(const mi_conv_desc d, const int N, const int MT, const int NT) {
+    constexpr int TM = 4, TN = 2, WN = 4, BM = 256, BN2 = 256, NST = 4;
+    constexpr int A_W = 4 * BM, SW = A_W + 4 * BN2;               // 16-byte words per stage: A image then B image (32 KiB)
+    __shared__ __attribute__((aligned(16))) uint4 smem[NST * SW];
+    {
+        float agpr_anchor = 0.f;
+        asm volatile("; accumulators in AGPRs %0" : "+a"(agpr_anchor));
+    }
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    // XCD-aware order: workgroups id, id + 8, ... share an L2; XCD x walks the N tiles nt = x (mod 8), the M tiles of one N
+    // tile back to back (they share the activation tile; the weights stay L2 resident)
+    const int xj = blockIdx.x >> 3;
+    const int nt = (xj / MT) * 8 + (blockIdx.x & 7), mt = xj % MT;
+    if (nt >= NT) return;                                          // grid padding (whole workgroup, before any barrier)
+    const int m0 = mt * BM, n0 = nt * BN2;
+    const int P = d.O1 * d.O2;
+    const int o2v = d.o2_valid ? d.o2_valid : d.O2;
+    const int nk = (d.Kpad + HK - 1) / HK;
+
+    // A: K step image = 4 octets x 256 rows = 16 wave instructions of 64 words; wave w issues 2 w and 2 w + 1 (octet w / 2,
+    // rows 128 (w & 1) + 64 j); B: the same over 256 columns.  Bases are wave-uniform, the lane offset is 16 lane.
+    const uint4 *wh = reinterpret_cast<const uint4 *>(d.wh);
+    const uint4 *xh = reinterpret_cast<const uint4 *>(d.xh);
+    const uint4 *zero = reinterpret_cast<const uint4 *>(d.sink + 256);
+    const int oct = wave >> 1, half = wave & 1;
+    const uint4 *abase = wh + (size_t)oct * d.Mpad + m0 + 128 * half;
+    const uint4 *bbase = xh + (size_t)oct * d.xh_n + n0 + 128 * half;
+    const size_t a_step = (size_t)4 * d.Mpad, b_step = (size_t)4 * d.xh_n;
+    const bool full_n = n0 + BN2 <= N;                              // wave-uniform: the ragged last column tile takes per-lane sources
+    const unsigned loff = 16u * lane;
+#define MI_IMG2_TILE(kt, stage)                                                                                      \
+    do {                                                                                                             \
+        uint4 *sa = smem + (stage) * SW + oct * BM + 128 * half, *sb = smem + (stage) * SW + A_W + oct * BN2 + 128 * half; \
+        const uint4 *ga = abase + (size_t)(kt) * a_step, *gb = bbase + (size_t)(kt) * b_step;                       \
+        lds_dma16_s(ga, loff, sa);                                                                                   \
+        lds_dma16_s(ga + 64, loff, sa + 64);                                                                         \
+        const bool kin = ((kt) * 4 + oct) * 8 < d.K;                                                                 \
+        if (full_n && kin) {                                                                                         \
+            lds_dma16_s(gb, loff, sb);                                                                               \
+            lds_dma16_s(gb + 64, loff, sb + 64);                                                                     \
+        } else {                                                                                                     \
+            const int c_ = n0 + 128 * half + lane;                                                                   \
+            lds_dma16((kin && c_ < N) ? gb + lane : zero, sb);                                                       \
+            lds_dma16((kin && c_ + 64 < N) ? gb + 64 + lane : zero, sb + 64);                                        \
+        }                                                                                                            \
+    } while (0)
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int li = lane & 31, lh = lane >> 5;
+    MI_IMG2_TILE(0, 0);
+    if (nk > 1) MI_IMG2_TILE(1, 1);
+    if (nk > 2) MI_IMG2_TILE(2, 2);
+    int stage = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        // tile kt has landed once all but this wave's two newest tiles (4 instructions each) are done -- for every wave
+        if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        // stage (kt + 3) % 4 was last read in the previous iteration, which every wave has finished
+        if (kt + 3 < nk) MI_IMG2_TILE(kt + 3, (stage + 3) & 3);
+        const uint4 *As = smem + stage * SW, *Bs = As + A_W;
+        uint4 af[2][TM], bf[2][TN];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+#pragma unroll
+            for (int a = 0; a < TM; ++a) af[s][a] = As[(2 * s + lh) * BM + (wm * TM + a) * 32 + li];
+#pragma unroll
+            for (int b = 0; b < TN; ++b) bf[s][b] = Bs[(2 * s + lh) * BN2 + (wn * TN + b) * 32 + li];
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b) acc[a][b] = mfma16<HT>(af[s][a], bf[s][b], acc[a][b]);
+        stage = (stage + 1) & 3;
+    }
+#undef MI_IMG2_TILE
+    conv_epilogue<TM, TN, MI_EPI_LINEAR, LFLAGS>(d, acc, m0, n0, wm, wn, N, P, o2v);
+}
+
+template <int HT, int LFLAGS>
+static int launch_half_img256(const mi_conv_desc &d, hipStream_t st) {
+    const int64_t N64 = (int64_t)d.B * d.O1 * d.O2;
+    MI_REQUIRE(N64 < (1ll << 31) - 256 && N64 <= d.xh_n, "conv: %lld output positions, operand image has %lld columns", (long long)N64,
+               (long long)d.xh_n);
+    MI_REQUIRE(d.Mpad % 256 == 0 && d.K % 8 == 0 && ((uintptr_t)d.xh & 15) == 0, "conv: operand-image layer (256-row tile) needs Mpad %% 256 == 0, K %% 8 == 0");
+    const int N = (int)N64, MT = d.Mpad / 256, NT = ceil_div(N, 256);
+    hipLaunchKernelGGL((conv_gemm_half_img256_kernel<HT, LFLAGS>), dim3((unsigned)(8 * MT * ((NT + 7) / 8))), dim3(512), 0, st, d, N, MT, NT);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+
 template <int HT, int TM, int LFLAGS>
 static int launch_half_img(const mi_conv_desc &d, hipStream_t st) {
     constexpr int BM = 2 * TM * 32;
@@ -385,10 +497,20 @@ static int launch_conv_half_t(const mi_conv_desc &d, int tile, bool plain, hipSt
     case E: return plain ? launch_tile_half<HT, E, 0, true>(d, tile, st) : launch_tile_half<HT, E, 0, false>(d, tile, st)
 #define MI_LINEAR(F)                                                \
     case F: return plain ? launch_tile_half<HT, MI_EPI_LINEAR, F, true>(d, tile, st) : launch_tile_half<HT, MI_EPI_LINEAR, F, false>(d, tile, st)
-    if (d.xh) {         // input given as a 16-bit operand image: the FFN's second linear layer
-        MI_REQUIRE(d.epi == MI_EPI_LINEAR && plain && (d.flags & (MI_FLAG_GELU | MI_FLAG_SCALE | MI_FLAG_RES | MI_FLAG_LN | MI_FLAG_IMG)) ==
-                   (MI_FLAG_SCALE | MI_FLAG_RES), "conv: an operand-image input is instantiated for plain LINEAR scale+residual layers");
-        return d.Mpad % 256 == 0 ? launch_half_img<HT, 4, MI_FLAG_SCALE | MI_FLAG_RES>(d, st) : launch_half_img<HT, 2, MI_FLAG_SCALE | MI_FLAG_RES>(d, st);
+    if (d.xh) {         // input given as a 16-bit operand image: lin2 / out_proj, and (256-row tile) the in-projections and lin1
+        const int f = d.flags & (MI_FLAG_GELU | MI_FLAG_SCALE | MI_FLAG_RES | MI_FLAG_LN | MI_FLAG_IMG | MI_FLAG_HEADS);
+        MI_REQUIRE(d.epi == MI_EPI_LINEAR && plain, "conv: an operand-image input needs a plain LINEAR layer");
+        // residual epilogues (out_proj, lin2: 340 MB of float32 residual read + output write per launch) keep the 256 x 128 tile
+        // at two workgroups per CU, whose epilogues overlap each other's main loops: measured 9.63 ms against 9.79 for the
+        // linear class with the 256 x 256 tile here (MI_IMG256=1: A/B switch)
+        static const bool img256 = [] { const char *e = getenv("MI_IMG256"); return e && atoi(e) != 0; }();
+        if (f == (MI_FLAG_SCALE | MI_FLAG_RES)) {
+            if (img256 && d.Mpad % 256 == 0) return launch_half_img256<HT, MI_FLAG_SCALE | MI_FLAG_RES>(d, st);
+            return d.Mpad % 256 == 0 ? launch_half_img<HT, 4, MI_FLAG_SCALE | MI_FLAG_RES>(d, st) : launch_half_img<HT, 2, MI_FLAG_SCALE | MI_FLAG_RES>(d, st);
+        }
+        if (f == (MI_FLAG_LN | MI_FLAG_HEADS)) return launch_half_img256<HT, MI_FLAG_LN | MI_FLAG_HEADS>(d, st);
+        if (f == (MI_FLAG_LN | MI_FLAG_GELU | MI_FLAG_IMG)) return launch_half_img256<HT, MI_FLAG_LN | MI_FLAG_GELU | MI_FLAG_IMG>(d, st);
+        return set_error(MI_EINVAL, "conv: an operand-image input is not instantiated for LINEAR flags %d", d.flags);
     }
     if (d.epi == MI_EPI_LINEAR) {
         switch (d.flags & (MI_FLAG_GELU | MI_FLAG_SCALE | MI_FLAG_RES | MI_FLAG_LN | MI_FLAG_IMG | MI_FLAG_HEADS)) {

@@ -26,11 +26,13 @@ int launch_finalize_stats(double *stats, int rows, double count, float eps, int 
                           hipStream_t st);
 int launch_row_affine(const float *x, int rows, int64_t count, const float2 *norm, float *y, hipStream_t st);
 int launch_row_denorm(const float *x, int rows, int64_t count, const float2 *denorm, float *y, hipStream_t st);
+// img (optional, half modes): the tensor the next matrix product reads, as its 16-bit operand image [C / 8][img_n][8]
 int launch_layernorm_cf(const float *x, int B, int C, int T, const float *w, const float *b, const float *pe, float *y,
-                        float2 *ostat, hipStream_t st);
-int launch_token_stats(const float *x, int B, int C, int T, float2 *ostat, hipStream_t st);
+                        float2 *ostat, hipStream_t st, void *img = nullptr, int64_t img_n = 0, int img_dtype = 0);
+int launch_token_stats(const float *x, int B, int C, int T, float2 *ostat, hipStream_t st, void *img = nullptr, int64_t img_n = 0,
+                       int img_dtype = 0);
 int launch_gn_apply_tokstats(const float *x, int B, int C, int T, const float2 *gstat, const float *w, const float *b, float *y,
-                             float2 *ostat, hipStream_t st);
+                             float2 *ostat, hipStream_t st, void *img = nullptr, int64_t img_n = 0, int img_dtype = 0);
 
 // GroupNorm(1) + GELU in place plus the Gram accumulators that give the NEXT GroupNorm's statistics (norms.hip)
 int gram_hp(int h);          // accumulator matrix order for h hidden channels: h + 1 rounded up to 32

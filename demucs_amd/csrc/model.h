@@ -87,6 +87,9 @@ struct WorkspacePtrs {
     float2 *w_tr_stat[2][2] = {}, *w_tr_stat1[2] = {};   // per-token (mean, rstd) of the layer inputs / of x1
     float *w_tr_x[2][2] = {}, *w_tr_qkv[2] = {}, *w_tr_att[2] = {}, *w_tr_x1[2] = {},
           *w_tr_x2[2] = {}, *w_tr_ffh[2] = {};
+    // half modes: 16-bit operand images [512 / 8][B tokens][8] of the layer inputs (beside w_tr_x) and of x1: what the
+    // in-projections and lin1 move global -> LDS by DMA
+    float *w_tr_ximg[2][2] = {}, *w_tr_x1img[2] = {};
     float *w_yspec = nullptr, *w_ytime = nullptr, *w_yt = nullptr, *w_fr = nullptr;
     double *w_stats = nullptr, *w_stats_t = nullptr, *w_gram = nullptr, *w_gram2 = nullptr;
     size_t gram2_bytes = 0;      // w_gram2: Gram accumulators of the implicit-GEMM DConv route (rows x slots x HP x HP float64)
@@ -153,7 +156,7 @@ struct Model : WorkspacePtrs {
     int run_dconv(const DConvW &w, int C, const Geo &g, float *x, float *tmp, float *hidden, double *stats, float2 *st1, float2 *st2,
                   hipStream_t st);
     int run_tr_layer(int br, int k, int B, const float *x, const float2 *xstat, const float *other, const float2 *ostat, float *out,
-                     float2 *outstat, hipStream_t st);
+                     float2 *outstat, hipStream_t st, const void *ximg = nullptr, const void *oimg = nullptr, void *outimg = nullptr);
 };
 
 }  // namespace mi

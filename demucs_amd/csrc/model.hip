@@ -586,6 +586,7 @@ int Model::fill_workspace(Workspace &w) {
     for (int br = 0; br < 2; ++br) {
         const size_t P = br ? Tt : Tf;
         MI_TRY(A(&w.w_tr_x[br][0], 512 * P)); MI_TRY(A(&w.w_tr_x[br][1], 512 * P));
+        MI_TRY(A(&w.w_tr_ximg[br][0], 256 * P)); MI_TRY(A(&w.w_tr_ximg[br][1], 256 * P)); MI_TRY(A(&w.w_tr_x1img[br], 256 * P));
         for (int q = 0; q < 2; ++q) MI_TRY(dev_alloc((void **)&w.w_tr_stat[br][q], B * P * sizeof(float2)));
         MI_TRY(dev_alloc((void **)&w.w_tr_stat1[br], B * P * sizeof(float2)));
         MI_TRY(A(&w.w_tr_qkv[br], 1536 * Tf)) /* cross layers: Q (512 x Tq) + KV (1024 x Tk) */; MI_TRY(A(&w.w_tr_att[br], 512 * P));
@@ -700,7 +701,7 @@ int Model::run_dconv(const DConvW &w, int C, const Geo &g, float *x, float *tmp,
 // LayerNorm statistics of every tensor that feeds a LayerNorm travelling beside it (xstat / ostat -> outstat):
 // the LayerNorms themselves are folded into the projections that consume them (MI_FLAG_LN).
 int Model::run_tr_layer(int br, int k, int B, const float *x, const float2 *xstat, const float *other, const float2 *ostat,
-                        float *out, float2 *outstat, hipStream_t st) {
+                        float *out, float2 *outstat, hipStream_t st, const void *ximg, const void *oimg, void *outimg) {
     const TrLayerW &l = tr[br][k];
     const bool cross = k & 1;
     const int Tf = 8 * T, Tt = Lt[4];
@@ -724,6 +725,7 @@ int Model::run_tr_layer(int br, int k, int B, const float *x, const float2 *xsta
         d.plain = 1; d.epi = MI_EPI_LINEAR; d.flags = MI_FLAG_LN; d.scale = l.qkv_c1; d.pro_stats = (const float *)xstat;
         d.y = qkv; d.y_bstride = (int64_t)1536 * Tq; d.y_cstride = Tq;
         if (heads) { d.flags |= MI_FLAG_HEADS; d.yh = qh; d.yh_n = Tq; }
+        if (heads && ximg) { d.xh = ximg; d.xh_n = (int64_t)B * Tq; }
         MI_TRY(conv(d, st));
         if (heads) MI_TRY(attn_heads(qh, qh + plane_q, qh + 2 * plane_q, att, B, Tq, Tq, st));
         else MI_TRY(attn(qkv, qkv + (size_t)512 * Tq, qkv + (size_t)1024 * Tq, att, B, Tq, Tq, (int64_t)1536 * Tq, (int64_t)1536 * Tq,
@@ -733,6 +735,7 @@ int Model::run_tr_layer(int br, int k, int B, const float *x, const float2 *xsta
         d.plain = 1; d.epi = MI_EPI_LINEAR; d.flags = MI_FLAG_LN; d.scale = l.q_c1; d.pro_stats = (const float *)xstat;
         d.y = qkv; d.y_bstride = (int64_t)512 * Tq; d.y_cstride = Tq;
         if (heads) { d.flags |= MI_FLAG_HEADS; d.yh = qh; d.yh_n = Tq; }
+        if (heads && ximg) { d.xh = ximg; d.xh_n = (int64_t)B * Tq; }
         MI_TRY(conv(d, st));
         float *kv = qkv + (size_t)B * 512 * Tq;
         unsigned short *kvh = qh + plane_q;
@@ -740,6 +743,7 @@ int Model::run_tr_layer(int br, int k, int B, const float *x, const float2 *xsta
         e.plain = 1; e.epi = MI_EPI_LINEAR; e.flags = MI_FLAG_LN; e.scale = l.kv_c1; e.pro_stats = (const float *)ostat;
         e.y = kv; e.y_bstride = (int64_t)1024 * Tk; e.y_cstride = Tk;
         if (heads) { e.flags |= MI_FLAG_HEADS; e.yh = kvh; e.yh_n = Tk; }
+        if (heads && oimg) { e.xh = oimg; e.xh_n = (int64_t)B * Tk; }
         MI_TRY(conv(e, st));
         if (heads) MI_TRY(attn_heads(qh, kvh, kvh + plane_k, att, B, Tq, Tk, st));
         else MI_TRY(attn(qkv, kv, kv + (size_t)512 * Tk, att, B, Tq, Tk, (int64_t)512 * Tq, (int64_t)1024 * Tk, (int64_t)512 * Tq, st, img));
@@ -751,13 +755,15 @@ int Model::run_tr_layer(int br, int k, int B, const float *x, const float2 *xsta
         if (img) { d.xh = att; d.xh_n = (int64_t)B * Tq; }
         MI_TRY(conv(d, st));
     }
-    MI_TRY(launch_token_stats(x1, B, 512, Tq, w_tr_stat1[br], st));
+    const bool in_img = heads && ximg != nullptr;        // the layer inputs and x1 exist as operand images too
+    MI_TRY(launch_token_stats(x1, B, 512, Tq, w_tr_stat1[br], st, in_img ? w_tr_x1img[br] : nullptr, (int64_t)B * Tq, cfg.dtype));
     {
         mi_conv_desc d = base_desc(l.lin1, tr_ktab512[br], x1, (int64_t)512 * Tq, gq);
         d.plain = 1; d.epi = MI_EPI_LINEAR; d.flags = MI_FLAG_LN | MI_FLAG_GELU; d.scale = l.lin1_c1;
         d.pro_stats = (const float *)w_tr_stat1[br];
         d.y = ffh; d.y_bstride = (int64_t)2048 * Tq; d.y_cstride = Tq;
         if (img) { d.flags |= MI_FLAG_IMG; d.yh = ffh; d.yh_n = (int64_t)B * Tq; }
+        if (img && in_img) { d.xh = w_tr_x1img[br]; d.xh_n = (int64_t)B * Tq; }
         MI_TRY(conv(d, st));
         mi_conv_desc e = base_desc(l.lin2, tr_ktab2048[br], ffh, (int64_t)2048 * Tq, gq);
         if (img) { e.xh = ffh; e.xh_n = (int64_t)B * Tq; }
@@ -769,7 +775,8 @@ int Model::run_tr_layer(int br, int k, int B, const float *x, const float2 *xsta
     // emits the per-token statistics the next layer's LayerNorms need
     MI_TRY(launch_row_stats(x2, B, (int64_t)512 * Tq, (int64_t)512 * Tq, stats, st));
     MI_TRY(launch_finalize_stats(stats, B, (double)512 * Tq, 1e-5f, 0, st1, nullptr, st));
-    MI_TRY(launch_gn_apply_tokstats(x2, B, 512, Tq, st1, l.norm_w[3], l.norm_b[3], out, outstat, st));
+    MI_TRY(launch_gn_apply_tokstats(x2, B, 512, Tq, st1, l.norm_w[3], l.norm_b[3], out, outstat, st, in_img ? outimg : nullptr,
+                                    (int64_t)B * Tq, cfg.dtype));
     return MI_OK;
 }
 
@@ -868,6 +875,9 @@ int Model::run_core_impl(const float *mix, const float *mag, int B, hipStream_t 
     }
     // ---- bottleneck: channel upsamplers, cross transformer, channel downsamplers -------------------
     int cur[2] = {0, 0};
+    // half modes: the transformer's projections read 16-bit operand images of their inputs (written by the token kernels)
+    static const bool no_in_img = getenv("MI_NO_INPUT_IMAGE") != nullptr || getenv("MI_NO_QKV_HEADS") != nullptr || getenv("MI_NO_FFN_IMAGE") != nullptr;
+    const bool in_img = cfg.dtype != MI_DTYPE_F32 && !no_in_img;
     for (int br = 0; br < 2; ++br) {
         const int P = br ? Tt : Tf;
         const Geo g{B, 1, P, 0};
@@ -875,14 +885,17 @@ int Model::run_core_impl(const float *mix, const float *mag, int B, hipStream_t 
         d.plain = 1; d.epi = MI_EPI_LINEAR; d.y = w_tr_x1[br]; d.y_bstride = (int64_t)512 * P; d.y_cstride = P;
         MI_TRY(conv(d, st));
         MI_TRY(launch_layernorm_cf(w_tr_x1[br], B, 512, P, norm_in_w[br], norm_in_b[br], pos_emb[br], w_tr_x[br][0],
-                                   w_tr_stat[br][0], st));
+                                   w_tr_stat[br][0], st, in_img ? w_tr_ximg[br][0] : nullptr, (int64_t)B * P, cfg.dtype));
     }
     MI_STAGE("upsample + norm_in done");
     for (int k = 0; k < 5; ++k) {
         const float *f_in = w_tr_x[0][cur[0]], *t_in = w_tr_x[1][cur[1]];
         const float2 *f_st = w_tr_stat[0][cur[0]], *t_st = w_tr_stat[1][cur[1]];
-        MI_TRY(run_tr_layer(0, k, B, f_in, f_st, t_in, t_st, w_tr_x[0][cur[0] ^ 1], w_tr_stat[0][cur[0] ^ 1], st));
-        MI_TRY(run_tr_layer(1, k, B, t_in, t_st, f_in, f_st, w_tr_x[1][cur[1] ^ 1], w_tr_stat[1][cur[1] ^ 1], st));
+        const void *f_img = in_img ? w_tr_ximg[0][cur[0]] : nullptr, *t_img = in_img ? w_tr_ximg[1][cur[1]] : nullptr;
+        MI_TRY(run_tr_layer(0, k, B, f_in, f_st, t_in, t_st, w_tr_x[0][cur[0] ^ 1], w_tr_stat[0][cur[0] ^ 1], st, f_img, t_img,
+                            w_tr_ximg[0][cur[0] ^ 1]));
+        MI_TRY(run_tr_layer(1, k, B, t_in, t_st, f_in, f_st, w_tr_x[1][cur[1] ^ 1], w_tr_stat[1][cur[1] ^ 1], st, t_img, f_img,
+                            w_tr_ximg[1][cur[1] ^ 1]));
         cur[0] ^= 1; cur[1] ^= 1;
         MI_STAGE("transformer layer done");
     }

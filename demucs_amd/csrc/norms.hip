@@ -88,11 +88,14 @@ __global__ __launch_bounds__(256) void row_affine_kernel(const float *__restrict
 //   MODE 1  per-token (mean, rstd) of x only -> ostat                      (LayerNorm folded into the next GEMM)
 //   MODE 2  GroupNorm(1) apply y = (x - gm[b]) * gr[b] * w[c] + b[c] -> y, and (mean, rstd) of y -> ostat
 // Variances use sums shifted by the token's first value (no cancellation), float32.
+// Half modes: `img` (optional) receives the tensor the NEXT matrix product reads -- y for MODE 0 / 2, x for MODE 1 -- as that
+// product's 16-bit operand image [C / 8][img_n][8] (column b T + t; gemm_half.hip): one coalesced 16-byte store per eight
+// channels and token, so that the projection moves it global -> LDS by DMA instead of loading and converting float32.
 template <int MODE>
 __global__ __launch_bounds__(256) void token_tile_kernel(const float *__restrict__ x, int C, int T, const float *__restrict__ w,
                                                          const float *__restrict__ bvec, const float *__restrict__ pe,
                                                          const float2 *__restrict__ gstat, float eps, float *__restrict__ y,
-                                                         float2 *__restrict__ ostat) {
+                                                         float2 *__restrict__ ostat, uint4 *__restrict__ img, int64_t img_n, int img_dtype) {
     __shared__ float red[4][64][2];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int t = blockIdx.x * 64 + lane;
@@ -104,6 +107,20 @@ __global__ __launch_bounds__(256) void token_tile_kernel(const float *__restrict
     if (MODE == 0 || MODE == 1) {                     // statistics of the input over channels
         const float x0 = x[base];
         float s1 = 0.f, s2 = 0.f;
+        if (MODE == 1 && img) {
+            for (int c = c0; c < c0 + cw; c += 8) {
+                float q[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    q[e] = x[base + (size_t)(c + e) * T];
+                    const float v = q[e] - x0;
+                    s1 += v; s2 += v * v;
+                }
+                if (ok) img[(size_t)(c >> 3) * img_n + (size_t)blockIdx.y * T + t] =
+                    make_uint4(pack_half2(img_dtype, q[0], q[1]), pack_half2(img_dtype, q[2], q[3]), pack_half2(img_dtype, q[4], q[5]),
+                               pack_half2(img_dtype, q[6], q[7]));
+            }
+        } else
         for (int c = c0; c < c0 + cw; ++c) {
             const float v = x[base + (size_t)c * T] - x0;
             s1 += v; s2 += v * v;
@@ -132,12 +149,20 @@ __global__ __launch_bounds__(256) void token_tile_kernel(const float *__restrict
         y0 = v;
     }
     float s1 = 0.f, s2 = 0.f;
+    float q8[8];
     for (int c = c0; c < c0 + cw; ++c) {
         float v = (x[base + (size_t)c * T] - mean) * rstd * w[c] + bvec[c];
         if (MODE == 0 && pe) v += pe[(size_t)c * T + (ok ? t : 0)];
         if (ok) y[base + (size_t)c * T] = v;
         const float dv = v - y0;
         s1 += dv; s2 += dv * dv;
+        if (img) {                                        // cw is a multiple of 8 (checked by the launcher)
+            q8[c & 7] = v;
+            if ((c & 7) == 7 && ok)
+                img[(size_t)(c >> 3) * img_n + (size_t)blockIdx.y * T + t] =
+                    make_uint4(pack_half2(img_dtype, q8[0], q8[1]), pack_half2(img_dtype, q8[2], q8[3]), pack_half2(img_dtype, q8[4], q8[5]),
+                               pack_half2(img_dtype, q8[6], q8[7]));
+        }
     }
     if (!ostat) return;
     red[wv][lane][0] = s1; red[wv][lane][1] = s2;
@@ -331,26 +356,37 @@ int launch_row_affine(const float *x, int rows, int64_t count, const float2 *nor
     return MI_OK;
 }
 
+static int check_img(int C, const void *img, int64_t img_n, int B, int T, int dtype) {
+    MI_REQUIRE(!img || (C % 32 == 0 && img_n >= (int64_t)B * T && ((uintptr_t)img & 15) == 0 && (dtype == MI_DTYPE_BF16 || dtype == MI_DTYPE_F16)),
+               "token kernel: operand image needs C %% 32 == 0, >= B * T columns, 16-byte alignment and a half dtype");
+    return MI_OK;
+}
+
 int launch_layernorm_cf(const float *x, int B, int C, int T, const float *w, const float *b, const float *pe, float *y,
-                        float2 *ostat, hipStream_t st) {
+                        float2 *ostat, hipStream_t st, void *img, int64_t img_n, int img_dtype) {
     MI_REQUIRE(C % 4 == 0, "layernorm: C %% 4 != 0");
-    hipLaunchKernelGGL(token_tile_kernel<0>, dim3(ceil_div(T, 64), B), dim3(256), 0, st, x, C, T, w, b, pe, nullptr, 1e-5f, y, ostat);
+    MI_TRY(check_img(C, img, img_n, B, T, img_dtype));
+    hipLaunchKernelGGL(token_tile_kernel<0>, dim3(ceil_div(T, 64), B), dim3(256), 0, st, x, C, T, w, b, pe, nullptr, 1e-5f, y, ostat,
+                       (uint4 *)img, img_n, img_dtype);
     MI_CHECK_LAUNCH();
     return MI_OK;
 }
 
-int launch_token_stats(const float *x, int B, int C, int T, float2 *ostat, hipStream_t st) {
+int launch_token_stats(const float *x, int B, int C, int T, float2 *ostat, hipStream_t st, void *img, int64_t img_n, int img_dtype) {
     MI_REQUIRE(C % 4 == 0, "token_stats: C %% 4 != 0");
+    MI_TRY(check_img(C, img, img_n, B, T, img_dtype));
     hipLaunchKernelGGL(token_tile_kernel<1>, dim3(ceil_div(T, 64), B), dim3(256), 0, st, x, C, T, nullptr, nullptr, nullptr, nullptr,
-                       1e-5f, nullptr, ostat);
+                       1e-5f, nullptr, ostat, (uint4 *)img, img_n, img_dtype);
     MI_CHECK_LAUNCH();
     return MI_OK;
 }
 
 int launch_gn_apply_tokstats(const float *x, int B, int C, int T, const float2 *gstat, const float *w, const float *b, float *y,
-                             float2 *ostat, hipStream_t st) {
+                             float2 *ostat, hipStream_t st, void *img, int64_t img_n, int img_dtype) {
     MI_REQUIRE(C % 4 == 0, "gn_apply: C %% 4 != 0");
-    hipLaunchKernelGGL(token_tile_kernel<2>, dim3(ceil_div(T, 64), B), dim3(256), 0, st, x, C, T, w, b, nullptr, gstat, 1e-5f, y, ostat);
+    MI_TRY(check_img(C, img, img_n, B, T, img_dtype));
+    hipLaunchKernelGGL(token_tile_kernel<2>, dim3(ceil_div(T, 64), B), dim3(256), 0, st, x, C, T, w, b, nullptr, gstat, 1e-5f, y, ostat,
+                       (uint4 *)img, img_n, img_dtype);
     MI_CHECK_LAUNCH();
     return MI_OK;
 }
