@@ -27,19 +27,12 @@ __device__ __forceinline__ float2 ld2(const float *p, bool ok) {
     return ok ? *reinterpret_cast<const float2 *>(p) : make_float2(0.f, 0.f);
 }
 
-constexpr int kGramPad = 96;        // doubles per wave for the reduced Gram entries (H (H + 1) / 2 + H <= 90)
-// slot of the n-th entry in the enumeration (i, k = i .. H) used by dconv_row_layer: k < H -> upper-triangle entry
-// (row-major), k == H -> NQ + i
-__device__ __forceinline__ constexpr int pend_slot(int n, int H) {
-    int i = 0;
-    while (n > H - i) { n -= H - i + 1; ++i; }
-    return n < H - i ? (i * (2 * H - i + 1)) / 2 + n : H * (H + 1) / 2 + i;
-}
+constexpr int kGramGroup = 16;      // Gram entries reduced per LDS round
 
 // one residual layer on the row: src -> dst (both [C][T] slices with channel stride cs; may alias)
 template <int C, int H, int DIL>
 __device__ __forceinline__ void dconv_row_layer(const DConvTimeLayer &LT, const float *src, float *dst, size_t cs, int T, float *wsm,
-                                                double *gred, bool row_ok) {
+                                                float *gpart, bool row_ok) {
     const DConvRowLayer &L = LT.w;
     constexpr int HA = (H + 3) / 4 * 4;
     constexpr int UNR = C >= 96 ? 1 : 2;      // channel-loop unrolling: the wider kernel has no registers to spare
@@ -71,15 +64,20 @@ __device__ __forceinline__ void dconv_row_layer(const DConvTimeLayer &LT, const 
 #pragma unroll
         for (int m = 0; m < HA / 2; ++m) hid[j][m] = (v2f){smalls[2 * m], smalls[2 * m + 1]};
     const bool has_l = on && t0 >= 2, has_r = on && t0 + kNC + 2 <= T;
+    // taps of channels c + 1 AND c + 2 are in flight under the products of channel c: with two or three waves per SIMD one
+    // channel ahead (72 packed FMAs ~ 0.15 us) does not cover an L2 / HBM round trip (SQ_WAIT_ANY was 40 % of the wave cycles)
     float2 n0 = ld2(src + t0 - 2, has_l), n1 = ld2(src + t0, on), n2 = ld2(src + t0 + 2, on), n3 = ld2(src + t0 + 4, on),
            n4 = ld2(src + t0 + 6, has_r);
+    float2 m0 = ld2(src + cs + t0 - 2, has_l), m1 = ld2(src + cs + t0, on), m2 = ld2(src + cs + t0 + 2, on), m3 = ld2(src + cs + t0 + 4, on),
+           m4 = ld2(src + cs + t0 + 6, has_r);
 #pragma unroll UNR
     for (int c = 0; c < C; ++c) {
         const v2f v[10] = {splat2(n0.x), splat2(n0.y), splat2(n1.x), splat2(n1.y), splat2(n2.x), splat2(n2.y), splat2(n3.x), splat2(n3.y),
                            splat2(n4.x), splat2(n4.y)};
-        if (c + 1 < C) {
-            const float *p = src + (c + 1) * cs + t0;
-            n0 = ld2(p - 2, has_l); n1 = ld2(p, on); n2 = ld2(p + 2, on); n3 = ld2(p + 4, on); n4 = ld2(p + 6, has_r);
+        n0 = m0; n1 = m1; n2 = m2; n3 = m3; n4 = m4;
+        if (c + 2 < C) {
+            const float *p = src + (c + 2) * cs + t0;
+            m0 = ld2(p - 2, has_l); m1 = ld2(p, on); m2 = ld2(p + 2, on); m3 = ld2(p + 4, on); m4 = ld2(p + 6, has_r);
         }
         const float4 *wv = reinterpret_cast<const float4 *>(w0s + c * 3 * HA);
 #pragma unroll
@@ -119,11 +117,27 @@ __device__ __forceinline__ void dconv_row_layer(const DConvTimeLayer &LT, const 
     //      sum z = colsum(W3) . s + T sum(b3),  sum z^2 = <W3^T W3, G> + 2 (W3^T b3) . s + T |b3|^2   (see dconv_time.hip)
     s1 = (double)T * LT.sum_b3; s2 = (double)T * LT.sum_b3sq;
     {
-        constexpr int NQ = H * (H + 1) / 2, NG = NQ + H;
-        double *gr = gred + (tid >> 6) * kGramPad;            // this wave's reduced Gram entries, then the sums s
-        float pend = 0.f;
-        int idx = 0;
-        // entries are reduced across the wave two at a time (one fp64 butterfly carries both)
+        constexpr int NG = H * (H + 1) / 2 + H;
+        // Every lane holds a float32 partial of each of the NG entries (its 6 columns).  Sixteen entries at a time go through this
+        // wave's LDS slab [16][64]: lane (entry e, quarter q) adds 16 of the 64 partials in float64, two shuffles join the quarters,
+        // and the entry's constants fold it straight into sum z^2 / sum z -- one LDS round per 16 entries instead of a six-level
+        // ds_bpermute butterfly per PAIR of entries (45 butterflies at H = 12: a third of the layer's time).
+        float *gp = gpart + (tid >> 6) * (kGramGroup * 64);
+        double cq = 0.0, cl = 0.0;
+        auto reduce_group = [&](int grp) {
+            const int e = lane >> 2, q = lane & 3, n = kGramGroup * grp + e;
+            const float4 *src4 = reinterpret_cast<const float4 *>(gp + e * 64 + 16 * q);
+            double sacc = 0.0;
+#pragma unroll
+            for (int v4 = 0; v4 < 4; ++v4) {
+                const float4 f = src4[v4];
+                sacc += (double)f.x; sacc += (double)f.y; sacc += (double)f.z; sacc += (double)f.w;
+            }
+            sacc += __shfl_xor(sacc, 1);
+            sacc += __shfl_xor(sacc, 2);
+            if (q == 0 && n < NG) { cq += LT.gram_e1[n] * sacc; cl += LT.gram_e2[n] * sacc; }
+        };
+        int n = 0;                                         // compile-time after unrolling
 #pragma unroll
         for (int i = 0; i < H; ++i) {
 #pragma unroll
@@ -131,29 +145,10 @@ __device__ __forceinline__ void dconv_row_layer(const DConvTimeLayer &LT, const 
                 float p = 0.f;
 #pragma unroll
                 for (int j = 0; j < kNC; ++j) p = k < H ? fmaf(g[j][i], g[j][k < H ? k : 0], p) : p + g[j][i];
-                const int slot = k < H ? (i * (2 * H - i + 1)) / 2 + (k - i) : NQ + i;
-                if (idx & 1) {
-                    double ra = (double)pend, rb = (double)p;
-                    wave_sum2(ra, rb);
-                    if (lane == 0) { gr[pend_slot(idx - 1, H)] = ra; gr[slot] = rb; }
-                    __builtin_amdgcn_sched_barrier(0);      // one butterfly at a time: interleaving them all would spill
-                } else {
-                    pend = p;
-                }
-                ++idx;
+                gp[(n & (kGramGroup - 1)) * 64 + lane] = p;
+                if ((n & (kGramGroup - 1)) == kGramGroup - 1 || n == NG - 1) reduce_group(n / kGramGroup);
+                ++n;
             }
-        }
-        if (idx & 1) {
-            double ra = (double)pend, rb = 0.0;
-            wave_sum2(ra, rb);
-            if (lane == 0) gr[pend_slot(idx - 1, H)] = ra;
-        }
-        __syncthreads();                                     // (uniform: every wave of the workgroup runs both layers)
-        double cq = 0.0, cl = 0.0;
-        for (int i = lane; i < NG; i += 64) {
-            const double G = gr[i];
-            if (i < NQ) cq += LT.gram_a[i] * G;
-            else { cq += LT.gram_v[i - NQ] * G; cl += LT.gram_c[i - NQ] * G; }
         }
         wave_sum2(cq, cl);
         s2 += cq; s1 += cl;
@@ -167,12 +162,14 @@ __device__ __forceinline__ void dconv_row_layer(const DConvTimeLayer &LT, const 
 #pragma unroll
         for (int m = 0; m < HA; ++m) gp[jp][m] = (v2f){g[2 * jp][m], g[2 * jp + 1][m]};
     float2 r0 = ld2(src + t0, on), r1 = ld2(src + t0 + 2, on), r2 = ld2(src + t0 + 4, on);
+    float2 q0 = ld2(src + cs + t0, on), q1 = ld2(src + cs + t0 + 2, on), q2 = ld2(src + cs + t0 + 4, on);
 #pragma unroll UNR
     for (int c = 0; c < C; ++c) {
-        const float r[kNC] = {r0.x, r0.y, r1.x, r1.y, r2.x, r2.y};
-        if (c + 1 < C) {
-            const float *p = src + (c + 1) * cs + t0;
-            r0 = ld2(p, on); r1 = ld2(p + 2, on); r2 = ld2(p + 4, on);
+        const v2f r[kNC / 2] = {(v2f){r0.x, r0.y}, (v2f){r1.x, r1.y}, (v2f){r2.x, r2.y}};
+        r0 = q0; r1 = q1; r2 = q2;
+        if (c + 2 < C) {
+            const float *p = src + (c + 2) * cs + t0;
+            q0 = ld2(p, on); q1 = ld2(p + 2, on); q2 = ld2(p + 4, on);
         }
         const float4 *wp = reinterpret_cast<const float4 *>(w3s + (size_t)c * HA * 4);
         v2f zv[kNC / 2], zg[kNC / 2];
@@ -187,16 +184,24 @@ __device__ __forceinline__ void dconv_row_layer(const DConvTimeLayer &LT, const 
                 zg[jp] = fma2((v2f){w.z, w.w}, gp[jp][k], zg[jp]);
             }
         }
-        // fold the GroupNorm affine: v = z * A + B
+        // GroupNorm affine folded (v = z A + B), GLU, LayerScale, residual: packed pairs of columns; the sigmoid's exponent takes
+        // the gate's affine with -log2(e) folded in
         const float aA = rs2 * g2ws[c], aB = g2bs[c] - mu2 * aA, gA = rs2 * g2ws[c + C], gB = g2bs[c + C] - mu2 * gA, sc = lss[c];
-        float o[kNC];
+        const v2f A2 = splat2(aA), B2 = splat2(aB), G2 = splat2(-1.44269504088896341f * gA), H2 = splat2(-1.44269504088896341f * gB),
+                  S2 = splat2(sc), one2 = splat2(1.0f);
+        v2f o[kNC / 2];
 #pragma unroll
-        for (int j = 0; j < kNC; ++j) o[j] = r[j] + sc * (fmaf(zv[j >> 1][j & 1], aA, aB) * sigmoid_f(fmaf(zg[j >> 1][j & 1], gA, gB)));
+        for (int jp = 0; jp < kNC / 2; ++jp) {
+            const v2f val = fma2(zv[jp], A2, B2), ex = fma2(zg[jp], G2, H2);
+            const v2f den = (v2f){__builtin_amdgcn_exp2f(ex.x), __builtin_amdgcn_exp2f(ex.y)} + one2;
+            const v2f sg = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+            o[jp] = fma2(val * sg, S2, r[jp]);
+        }
         if (on) {
             float *q = dst + c * cs + t0;
-            *reinterpret_cast<float2 *>(q) = make_float2(o[0], o[1]);
-            *reinterpret_cast<float2 *>(q + 2) = make_float2(o[2], o[3]);
-            *reinterpret_cast<float2 *>(q + 4) = make_float2(o[4], o[5]);
+            *reinterpret_cast<float2 *>(q) = make_float2(o[0].x, o[0].y);
+            *reinterpret_cast<float2 *>(q + 2) = make_float2(o[1].x, o[1].y);
+            *reinterpret_cast<float2 *>(q + 4) = make_float2(o[2].x, o[2].y);
         }
     }
     __threadfence_block();                  // the next layer's taps read other lanes' columns of dst
@@ -206,14 +211,14 @@ template <int C, int H>
 __global__ __launch_bounds__(64 * kRowsPerBlock, 2) void dconv_row_kernel(const DConvRowArgs a, int rows) {
     constexpr int HA = (H + 3) / 4 * 4;
     __shared__ __attribute__((aligned(16))) float wsm[C * 3 * HA + 4 * C * HA + 7 * C + 3 * HA];
-    __shared__ double gred[kRowsPerBlock * kGramPad];
+    __shared__ __attribute__((aligned(16))) float gpart[kRowsPerBlock * kGramGroup * 64];
     const int row = blockIdx.x * kRowsPerBlock + (threadIdx.x >> 6);
     const bool row_ok = row < rows;
     const int rr = row_ok ? row : 0, b = rr / a.Fr, fr = rr - b * a.Fr;
     const size_t cs = (size_t)a.Fr * a.T;
     const size_t off = ((size_t)b * C * a.Fr + fr) * a.T;
-    dconv_row_layer<C, H, 1>(a.l[0], a.x + off, a.y + off, cs, a.T, wsm, gred, row_ok);
-    dconv_row_layer<C, H, 2>(a.l[1], a.y + off, a.y + off, cs, a.T, wsm, gred, row_ok);
+    dconv_row_layer<C, H, 1>(a.l[0], a.x + off, a.y + off, cs, a.T, wsm, gpart, row_ok);
+    dconv_row_layer<C, H, 2>(a.l[1], a.y + off, a.y + off, cs, a.T, wsm, gpart, row_ok);
 }
 
 bool dconv_row_supported(int C, int T) { return (C == 48 || C == 96) && T % kNC == 0 && T % 2 == 0 && T / kNC <= 64; }

@@ -59,6 +59,8 @@ struct DConvTimeLayer {
     const double *gram_a;        // [H (H + 1) / 2]  (W3^T W3)_ii, then 2 (W3^T W3)_ik for k > i, row-major upper triangle
     const double *gram_v;        // [H]              2 W3^T b3
     const double *gram_c;        // [H]              column sums of W3
+    const double *gram_e1, *gram_e2;   // [H (H + 1) / 2 + H] the same constants in the ENTRY order of dconv_row.hip's reduction
+                                 //   (i, k = i .. H): weight of the entry in sum z^2 / in sum z
     double sum_b3, sum_b3sq;
 };
 struct DConvRowArgs {

@@ -325,9 +325,14 @@ int Model::load_dconv(const WeightTable &wt, const std::string &prefix, int C, i
                         gc[i] += (double)w3[(size_t)m * h + i];
                     }
                 }
-                double *da, *dv, *dc;
-                MI_TRY(upload(ga, &da)); MI_TRY(upload(gv, &dv)); MI_TRY(upload(gc, &dc));
-                dw->tl[d] = DConvTimeLayer{dw->row[d], da, dv, dc, sb, sbq};
+                std::vector<double> e1, e2;          // entry order (i, k = i .. h): k < h -> (W3^T W3 term, 0), k == h -> (2 W3^T b3, colsum)
+                for (int i = 0, q = 0; i < h; ++i) {
+                    for (int k = i; k < h; ++k) { e1.push_back(ga[q++]); e2.push_back(0.0); }
+                    e1.push_back(gv[i]); e2.push_back(gc[i]);
+                }
+                double *da, *dv, *dc, *de1, *de2;
+                MI_TRY(upload(ga, &da)); MI_TRY(upload(gv, &dv)); MI_TRY(upload(gc, &dc)); MI_TRY(upload(e1, &de1)); MI_TRY(upload(e2, &de2));
+                dw->tl[d] = DConvTimeLayer{dw->row[d], da, dv, dc, de1, de2, sb, sbq};
             }
         }
     }
