@@ -10,12 +10,15 @@
 // apply) instead of storing its 2C-wide result, activations come in as aligned float2 loads, weights are
 // broadcast from LDS (one ds_read_b128 feeds 24 FMAs) and shared by the 4 rows of a workgroup.
 // fp32 VALU FMAs: the contraction lengths (3C and C/8) are far too short for MFMA tiles to pay (M = 6 or 12).
+#include <algorithm>
+
 #include "common.h"
 #include "kernels.h"
 
 namespace mi {
 
-constexpr int kRowsPerBlock = 4;   // one wave per row
+// Persistent workgroups: both layers' weights are staged into LDS ONCE per workgroup, then every wave walks rows on its own
+// (row = first + k * stride) -- no barrier after the staging, no re-staging per group of four rows.
 constexpr int kNC = 6;             // columns per lane
 
 __device__ __forceinline__ void wave_sum2(double &a, double &b) {
@@ -30,10 +33,29 @@ __device__ __forceinline__ float2 ld2(const float *p, bool ok) {
 constexpr int kGramGroup = 16;      // Gram entries reduced per LDS round
 
 // one residual layer on the row: src -> dst (both [C][T] slices with channel stride cs; may alias)
+// LDS image of one layer's weights (floats): w0 [C][3][HA], w3 pre-splatted [C][HA][4], b3 / g2w / g2b [2C] each, ls [C], b0 / g1w / g1b [HA] each
+template <int C, int H>
+__device__ __forceinline__ constexpr int dconv_row_wsm() { return C * 3 * ((H + 3) / 4 * 4) + 4 * C * ((H + 3) / 4 * 4) + 7 * C + 3 * ((H + 3) / 4 * 4); }
+
+template <int C, int H, int NT>
+__device__ __forceinline__ void dconv_row_stage(const DConvRowLayer &L, float *wsm) {
+    constexpr int HA = (H + 3) / 4 * 4;
+    float *w0s = wsm, *w3s = w0s + C * 3 * HA, *b3s = w3s + 4 * C * HA, *g2ws = b3s + 2 * C, *g2bs = g2ws + 2 * C, *lss = g2bs + 2 * C,
+          *smalls = lss + C;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < C * 3 * HA; i += NT) w0s[i] = L.w0[i];
+    for (int i = tid; i < 4 * C * HA; i += NT) {
+        const int half = (i >> 1) & 1, k = (i >> 2) % HA, c = (i >> 2) / HA;
+        w3s[i] = L.w3[(size_t)(c + half * C) * HA + k];
+    }
+    for (int i = tid; i < 2 * C; i += NT) { b3s[i] = L.b3[i]; g2ws[i] = L.g2w[i]; g2bs[i] = L.g2b[i]; }
+    for (int i = tid; i < C; i += NT) lss[i] = L.ls[i];
+    if (tid < HA) { smalls[tid] = L.b0[tid]; smalls[HA + tid] = L.g1w[tid]; smalls[2 * HA + tid] = L.g1b[tid]; }
+}
+
 template <int C, int H, int DIL>
 __device__ __forceinline__ void dconv_row_layer(const DConvTimeLayer &LT, const float *src, float *dst, size_t cs, int T, float *wsm,
                                                 float *gpart, bool row_ok) {
-    const DConvRowLayer &L = LT.w;
     constexpr int HA = (H + 3) / 4 * 4;
     constexpr int UNR = C >= 96 ? 1 : 2;      // channel-loop unrolling: the wider kernel has no registers to spare
     float *w0s = wsm;                       // [C][3][HA]
@@ -45,16 +67,6 @@ __device__ __forceinline__ void dconv_row_layer(const DConvTimeLayer &LT, const 
     const int tid = threadIdx.x, lane = tid & 63, nq = T / kNC;
     const bool on = row_ok && lane < nq;
     const int t0 = (lane < nq ? lane : 0) * kNC;
-    __syncthreads();                        // previous layer is done with the LDS weights
-    for (int i = tid; i < C * 3 * HA; i += 64 * kRowsPerBlock) w0s[i] = L.w0[i];
-    for (int i = tid; i < 4 * C * HA; i += 64 * kRowsPerBlock) {
-        const int half = (i >> 1) & 1, k = (i >> 2) % HA, c = (i >> 2) / HA;
-        w3s[i] = L.w3[(size_t)(c + half * C) * HA + k];
-    }
-    for (int i = tid; i < 2 * C; i += 64 * kRowsPerBlock) { b3s[i] = L.b3[i]; g2ws[i] = L.g2w[i]; g2bs[i] = L.g2b[i]; }
-    for (int i = tid; i < C; i += 64 * kRowsPerBlock) lss[i] = L.ls[i];
-    if (tid < HA) { smalls[tid] = L.b0[tid]; smalls[HA + tid] = L.g1w[tid]; smalls[2 * HA + tid] = L.g1b[tid]; }
-    __syncthreads();
 
     // ---- dilated conv3: taps cover columns t0-2 .. t0+7, fetched as five float2, one channel ahead; hidden channels
     //      in pairs: one v_pk_fma_f32 (two IEEE fmas) per tap and pair ---------------------------------------------
@@ -122,7 +134,7 @@ __device__ __forceinline__ void dconv_row_layer(const DConvTimeLayer &LT, const 
         // wave's LDS slab [16][64]: lane (entry e, quarter q) adds 16 of the 64 partials in float64, two shuffles join the quarters,
         // and the entry's constants fold it straight into sum z^2 / sum z -- one LDS round per 16 entries instead of a six-level
         // ds_bpermute butterfly per PAIR of entries (45 butterflies at H = 12: a third of the layer's time).
-        float *gp = gpart + (tid >> 6) * (kGramGroup * 64);
+        float *gp = gpart;
         double cq = 0.0, cl = 0.0;
         auto reduce_group = [&](int grp) {
             const int e = lane >> 2, q = lane & 3, n = kGramGroup * grp + e;
@@ -207,18 +219,22 @@ __device__ __forceinline__ void dconv_row_layer(const DConvTimeLayer &LT, const 
     __threadfence_block();                  // the next layer's taps read other lanes' columns of dst
 }
 
-template <int C, int H>
-__global__ __launch_bounds__(64 * kRowsPerBlock, 2) void dconv_row_kernel(const DConvRowArgs a, int rows) {
-    constexpr int HA = (H + 3) / 4 * 4;
-    __shared__ __attribute__((aligned(16))) float wsm[C * 3 * HA + 4 * C * HA + 7 * C + 3 * HA];
-    __shared__ __attribute__((aligned(16))) float gpart[kRowsPerBlock * kGramGroup * 64];
-    const int row = blockIdx.x * kRowsPerBlock + (threadIdx.x >> 6);
-    const bool row_ok = row < rows;
-    const int rr = row_ok ? row : 0, b = rr / a.Fr, fr = rr - b * a.Fr;
+template <int C, int H, int NW>
+__global__ __launch_bounds__(64 * NW) void dconv_row_kernel(const DConvRowArgs a, int rows) {
+    constexpr int WS = (dconv_row_wsm<C, H>() + 3) / 4 * 4;
+    __shared__ __attribute__((aligned(16))) float wsm[2 * WS];
+    __shared__ __attribute__((aligned(16))) float gpart[NW * kGramGroup * 64];
+    dconv_row_stage<C, H, 64 * NW>(a.l[0].w, wsm);
+    dconv_row_stage<C, H, 64 * NW>(a.l[1].w, wsm + WS);
+    __syncthreads();
     const size_t cs = (size_t)a.Fr * a.T;
-    const size_t off = ((size_t)b * C * a.Fr + fr) * a.T;
-    dconv_row_layer<C, H, 1>(a.l[0], a.x + off, a.y + off, cs, a.T, wsm, gpart, row_ok);
-    dconv_row_layer<C, H, 2>(a.l[1], a.y + off, a.y + off, cs, a.T, wsm, gpart, row_ok);
+    float *gp = gpart + (threadIdx.x >> 6) * (kGramGroup * 64);
+    for (int row = blockIdx.x * NW + (threadIdx.x >> 6); row < rows; row += gridDim.x * NW) {
+        const int b = row / a.Fr, fr = row - b * a.Fr;
+        const size_t off = ((size_t)b * C * a.Fr + fr) * a.T;
+        dconv_row_layer<C, H, 1>(a.l[0], a.x + off, a.y + off, cs, a.T, wsm, gp, true);
+        dconv_row_layer<C, H, 2>(a.l[1], a.y + off, a.y + off, cs, a.T, wsm + WS, gp, true);
+    }
 }
 
 bool dconv_row_supported(int C, int T) { return (C == 48 || C == 96) && T % kNC == 0 && T % 2 == 0 && T / kNC <= 64; }
@@ -226,9 +242,16 @@ bool dconv_row_supported(int C, int T) { return (C == 48 || C == 96) && T % kNC 
 int launch_dconv_row(const DConvRowArgs &a, int C, int rows, hipStream_t st) {
     MI_REQUIRE(dconv_row_supported(C, a.T), "dconv_row: unsupported C=%d T=%d", C, a.T);
     MI_REQUIRE(((uintptr_t)a.x & 7) == 0 && ((uintptr_t)a.y & 7) == 0, "dconv_row: tensors must be 8-byte aligned");
-    const int nblk = ceil_div(rows, kRowsPerBlock);
-    if (C == 48) hipLaunchKernelGGL((dconv_row_kernel<48, 6>), dim3(nblk), dim3(64 * kRowsPerBlock), 0, st, a, rows);
-    else hipLaunchKernelGGL((dconv_row_kernel<96, 12>), dim3(nblk), dim3(64 * kRowsPerBlock), 0, st, a, rows);
+    static const int cus = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
+    // C = 48: 4-wave workgroups (40 KiB of LDS: three per CU by LDS, registers allow three waves per SIMD);
+    // C = 96: 8-wave workgroups (102 KiB: one per CU, two waves per SIMD as the 200 registers allow)
+    if (C == 48) {
+        const int nblk = std::min(ceil_div(rows, 4), 3 * cus);
+        hipLaunchKernelGGL((dconv_row_kernel<48, 6, 4>), dim3(nblk), dim3(256), 0, st, a, rows);
+    } else {
+        const int nblk = std::min(ceil_div(rows, 8), cus);
+        hipLaunchKernelGGL((dconv_row_kernel<96, 12, 8>), dim3(nblk), dim3(512), 0, st, a, rows);
+    }
     MI_CHECK_LAUNCH();
     return MI_OK;
 }
