@@ -170,7 +170,7 @@ def main():
             bound, achieved, peak, unit = "mfma", algo_tflops * (X6_PRODUCTS if x6 else 1), MFMA_PEAK_TFLOPS[pipe], "TFLOP/s"
         total_ms = sum(r["ms"] for r in rows)
         traffic, traffic_src = None, None        # HBM bytes per launch from the committed PMC passes of this same command
-        for tname in ("round2_traffic.json", "round1_traffic.json"):
+        for tname in ("round3_traffic.json", "round2_traffic.json", "round1_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", tname)
             if traffic is None and os.path.exists(tpath) and world == 1 and args.batch == 32 and seconds == TRACK_SECONDS:
                 entry = json.load(open(tpath)).get(dom["name"] + ("" if args.dtype == "f32" else "@" + args.dtype))
@@ -182,6 +182,9 @@ def main():
         result = {
             "metric": "real-time factor (audio-sec/wall-sec) htdemucs 4-stem 44.1kHz stereo, 1/8 GPU",
             "value": round(length / SR / sec_per_step, 2), "unit": "audio-sec/wall-sec",
+            "value_span": "mix resident in HBM when the clock starts, stems left in HBM (the bench contract); SURVEY.md 8(d)'s span -- host "
+                          "mix in, host stems out, PCIe inclusive -- is `host_to_host` below, and the user-facing Separator entry "
+                          "`separator_host_to_host`",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(sec_per_step * 1e3, 3),
             "higher_is_better": True, "scaling": "strong" if multi else "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
@@ -312,10 +315,26 @@ def main():
                 torch.cuda.synchronize(dev)
                 times.append(time.perf_counter() - t1)
             dt_s = sorted(times)[1]                       # median of three passes
+            # what bounds this mode: the BLSTM recurrence of encoder layers 4 / 5 -- 1 600 DEPENDENT launches per forward, so a
+            # latency chain, not a bandwidth or matrix-pipe figure: timed (HIP events on the launch stream) in one more pass
+            hm.profile_begin()
+            P.apply_model(hbag, hmix, shifts=0, split=True, overlap=0.25, device=dev)
+            hrows = hm.profile_end()
+            lstm = [r for r in hrows if r["name"] == "lstm_step_kernel"]
+            BOUNDARY_US = 1.45        # MI355X_MICROARCH.md price list, row "boundary": dependent kernel boundary on one stream
+            h_roof = None
+            if lstm:
+                us = lstm[0]["ms"] * 1e3 / lstm[0]["launches"]
+                h_roof = {"bound": "latency", "kernel": "lstm_step_kernel", "launches": lstm[0]["launches"], "avg_launch_us": round(us, 3),
+                          "floor_us": BOUNDARY_US, "frac": round(BOUNDARY_US / us, 4), "chain_ms": round(lstm[0]["ms"], 3),
+                          "share_of_step": round(lstm[0]["ms"] * 1e-3 / dt_s, 3),
+                          "note": "main engine's batched forward only (the tail chunk's own 1 600 launches run under it on the side "
+                                  "stream); floor = one dependent kernel boundary per time step; peak / achieved in microseconds per launch",
+                          "achieved": round(us, 3), "peak": BOUNDARY_US, "unit": "us/launch"}
             assert o.shape == (1, 4, 2, TRACK_SECONDS * SR) and bool(torch.isfinite(o[0, :, 0, ::997]).all())
             result["modes"]["hdemucs_mmi fp16"] = {"dtype": "f16", "sources": 4, "value": round(TRACK_SECONDS / dt_s, 2), "unit": "audio-sec/wall-sec",
                                                    "ms_per_step": round(dt_s * 1e3, 2), "steps": 3,
-                                                   "device_bytes": hm.device_bytes(),
+                                                   "device_bytes": hm.device_bytes(), "roofline": h_roof,
                                                    "note": "6 chunks (overlap 0.25): five of 44 s in one batched forward, the 15 s tail on the side engine and a side stream under it"}
             del o, hmix
             hm.release()

@@ -372,8 +372,8 @@ def _leaf_valid_length(model: HTDemucs, segment_length: int, segment) -> int:
     return valid
 
 
-def device_split_accumulate(model: HTDemucs, base: torch.Tensor, chunk_offset: int, length: int, offsets: Sequence[int],
-                            segment_length: int, valid_length: int, weight: torch.Tensor, acc: torch.Tensor, acc_origin: int,
+def device_split_accumulate(model: HTDemucs, base, chunk_offset: int, length: int, offsets: Sequence[int],
+                            segment_length: int, valid_length: int, weight: torch.Tensor, acc, acc_origin: int,
                             on_start: Optional[Callable[[int], None]] = None, on_end: Optional[Callable[[int], None]] = None,
                             draw_rng: bool = True, base_origin: int = 0) -> None:
     """Run the segments at `offsets` (relative to the chunk that starts at `chunk_offset` of the
@@ -393,54 +393,72 @@ def device_split_accumulate(model: HTDemucs, base: torch.Tensor, chunk_offset: i
     if segment_length > valid_length or weight.numel() < segment_length:
         raise ValueError(f"segment length {segment_length} does not fit the padded length {valid_length} / the weight "
                          f"ramp ({weight.numel()})")
+    # several TRACKS of equal geometry (a batch of mixes): `base` and `acc` are sequences; the segments of one offset group
+    # of ALL tracks share one batched forward, as the reference forwards all tracks of an offset in one model call
+    bases = [base] if isinstance(base, torch.Tensor) else list(base)
+    accs = [acc] if isinstance(acc, torch.Tensor) else list(acc)
+    assert len(bases) == len(accs) and all(b.shape == bases[0].shape for b in bases) and all(a.shape == accs[0].shape for a in accs)
+    n_tracks = len(bases)
     lib = _lib.load()
-    dev = base.device
-    channels, total = base.shape
-    rows = acc.shape[0]
+    dev = bases[0].device
+    channels, total = bases[0].shape
+    rows = accs[0].shape[0]
     stream = lambda: C.c_void_p(_lib.current_stream_ptr())          # noqa: E731
     B = model.max_batch
+    per = max(1, B // n_tracks)        # offsets per forward: per * n_tracks segments (one track at a time when max_batch < n_tracks)
+    group = n_tracks if B >= n_tracks else 1
     SL = model.segment_length          # the engine's fixed forward length; a shorter leaf window is
     short = valid_length < SL          # right-padded with zeros like HTDemucs.forward does (htdemucs.py:534-537)
     seg_buf = torch.zeros(B, channels, SL, device=dev, dtype=torch.float32)
     cut_buf = torch.empty(B, channels, valid_length, device=dev, dtype=torch.float32) if short else seg_buf
     out_buf = torch.empty(B, rows // channels, channels, SL, device=dev, dtype=torch.float32)
     with torch.cuda.device(dev):
-        for i0 in range(0, len(offsets), B):
-            offs = list(offsets[i0:i0 + B])
-            nb = len(offs)
-            lens = [min(length - o, segment_length) for o in offs]
-            trims = [(valid_length - n) // 2 for n in lens]
-            starts = [chunk_offset + o - t - base_origin for o, t in zip(offs, trims)]     # TensorChunk.padded window
-            # index tensors stay referenced until the launches below are enqueued: the caching allocator
-            # may hand a dropped tensor's block to the next allocation before the kernel has read it
-            t_starts = _i64(starts, dev)
-            _lib.check(lib.mi_segments_gather(base.data_ptr(), total, channels, t_starts.data_ptr(), nb, valid_length,
-                                              cut_buf.data_ptr(), cut_buf.numel(), stream()), "mi_segments_gather")
-            if short:
-                seg_buf[:nb, :, :valid_length] = cut_buf[:nb]
-            # the overlap-add's index tensors go to the device BEFORE the forward is enqueued: a host -> device copy issued
-            # behind it would hold the host (and the next launch) until the forward has drained
-            acc_offs = [o - acc_origin for o in offs]
-            t_offs, t_lens, t_trims = _i64(acc_offs, dev), _i32(lens, dev), _i32(trims, dev)
-            if on_start is not None:
-                on_start(offs[0])
-            model.forward_segments(seg_buf[:nb], out_buf[:nb])
-            if on_end is not None:
-                torch.cuda.current_stream(dev).synchronize()      # "end" means computed, as after the reference's blocking leaf
-            for k, o in enumerate(offs):
-                if draw_rng:
-                    random.randrange(1)              # transformer.py:680, once per segment forward (whole batch of tracks)
-                if k and on_start is not None:
-                    on_start(o)
-                if on_end is not None:
-                    on_end(o)
-            # a segment may hang over either end of `acc` (a rank's slab of a shifted pass): only the part inside counts
-            span_lo, span_hi = max(0, min(acc_offs)), min(acc.shape[1], max(a + n for a, n in zip(acc_offs, lens)))
-            if span_hi <= span_lo:
-                continue
-            _lib.check(lib.mi_ola_accumulate(acc.data_ptr(), acc.shape[1], rows, out_buf.data_ptr(), SL, out_buf.numel(),
-                                             t_offs.data_ptr(), t_lens.data_ptr(), t_trims.data_ptr(), nb, span_lo,
-                                             span_hi, weight.data_ptr(), weight.numel(), stream()), "mi_ola_accumulate")
+        for g0 in range(0, n_tracks, group):
+            tracks = list(range(g0, min(n_tracks, g0 + group)))
+            first_group = g0 == 0
+            for i0 in range(0, len(offsets), per):
+                offs = list(offsets[i0:i0 + per])
+                nb = len(offs)
+                lens = [min(length - o, segment_length) for o in offs]
+                trims = [(valid_length - n) // 2 for n in lens]
+                starts = [chunk_offset + o - t - base_origin for o, t in zip(offs, trims)]     # TensorChunk.padded window
+                # index tensors stay referenced until the launches below are enqueued: the caching allocator
+                # may hand a dropped tensor's block to the next allocation before the kernel has read it
+                t_starts = _i64(starts, dev)
+                for k, tr in enumerate(tracks):
+                    dst = cut_buf[k * nb:(k + 1) * nb]
+                    _lib.check(lib.mi_segments_gather(bases[tr].data_ptr(), total, channels, t_starts.data_ptr(), nb, valid_length,
+                                                      dst.data_ptr(), dst.numel(), stream()), "mi_segments_gather")
+                ntot = nb * len(tracks)
+                if short:
+                    seg_buf[:ntot, :, :valid_length] = cut_buf[:ntot]
+                # the overlap-add's index tensors go to the device BEFORE the forward is enqueued: a host -> device copy issued
+                # behind it would hold the host (and the next launch) until the forward has drained
+                acc_offs = [o - acc_origin for o in offs]
+                t_offs, t_lens, t_trims = _i64(acc_offs, dev), _i32(lens, dev), _i32(trims, dev)
+                listen = first_group
+                if on_start is not None and listen:
+                    on_start(offs[0])
+                model.forward_segments(seg_buf[:ntot], out_buf[:ntot])
+                if on_end is not None and listen:
+                    torch.cuda.current_stream(dev).synchronize()      # "end" means computed, as after the reference's blocking leaf
+                if listen:
+                    for k, o in enumerate(offs):
+                        if draw_rng:
+                            random.randrange(1)              # transformer.py:680, once per segment forward (whole batch of tracks)
+                        if k and on_start is not None:
+                            on_start(o)
+                        if on_end is not None:
+                            on_end(o)
+                # a segment may hang over either end of `acc` (a rank's slab of a shifted pass): only the part inside counts
+                span_lo, span_hi = max(0, min(acc_offs)), min(accs[0].shape[1], max(a + n for a, n in zip(acc_offs, lens)))
+                if span_hi <= span_lo:
+                    continue
+                for k, tr in enumerate(tracks):
+                    src = out_buf[k * nb:(k + 1) * nb]
+                    _lib.check(lib.mi_ola_accumulate(accs[tr].data_ptr(), accs[tr].shape[1], rows, src.data_ptr(), SL, src.numel(),
+                                                     t_offs.data_ptr(), t_lens.data_ptr(), t_trims.data_ptr(), nb, span_lo,
+                                                     span_hi, weight.data_ptr(), weight.numel(), stream()), "mi_ola_accumulate")
 
 
 def ragged_split_accumulate(model: HDemucs, base: torch.Tensor, chunk_offset: int, length: int, offsets: Sequence[int],
@@ -574,20 +592,32 @@ def _apply_split_device(model, mix, common, callback, callback_arg) -> torch.Ten
         if bar is not None:
             bar.update(1)
 
+    if not ragged:
+        # the reference forwards all `batch` tracks of a segment offset in ONE model call (one RNG draw and one start / end event
+        # pair per offset): here the tracks' segments of an offset group share one batched forward as well
+        bases = [chunk.tensor[b].to(device=device, dtype=torch.float32).contiguous() for b in range(batch)]       # resident in HBM
+        accs = [out[b].view(S * channels, length) if on_device else torch.zeros(S * channels, length, device=device, dtype=torch.float32)
+                for b in range(batch)]
+        fin = finish_index(length, offsets, segment_length, device)
+        listen = callback is not None or bar is not None        # without a listener nothing waits for the forwards
+        device_split_accumulate(model, bases, chunk.offset, length, offsets, segment_length, valid_length, weight, accs, 0,
+                                on_start if listen else None, on_end if listen else None, draw_rng=True)
+        for b in range(batch):
+            device_split_finish(accs[b], 0, length, offsets, segment_length, weight, fin)
+            if not on_device:
+                out[b] = accs[b].view(S, channels, length).to(mix.device)
+        if bar is not None:
+            bar.close()
+        return out
     for b in range(batch):
-        # the reference forwards all `batch` tracks of a segment offset in ONE model call: one RNG draw and one
-        # start/end event pair per offset, not per (track, offset)
+        # HDemucs (ragged route): one track at a time; events and the progress bar follow the first track
         first = b == 0
         base = chunk.tensor[b].to(device=device, dtype=torch.float32).contiguous()       # whole track resident in HBM
         acc = out[b].view(S * channels, length) if on_device else torch.zeros(S * channels, length, device=device, dtype=torch.float32)
         fin = finish_index(length, offsets, segment_length, device)
-        if ragged:
-            listen = first and (callback is not None or bar is not None)     # no listener: the tail chunk may overlap the others
-            ragged_split_accumulate(model, base, chunk.offset, length, offsets, segment_length, weight, acc,
-                                    on_start if listen else None, on_end if listen else None)
-        else:
-            device_split_accumulate(model, base, chunk.offset, length, offsets, segment_length, valid_length, weight, acc, 0,
-                                    on_start if first else None, on_end if first else None, draw_rng=first)
+        listen = first and (callback is not None or bar is not None)     # no listener: the tail chunk may overlap the others
+        ragged_split_accumulate(model, base, chunk.offset, length, offsets, segment_length, weight, acc,
+                                on_start if listen else None, on_end if listen else None)
         device_split_finish(acc, 0, length, offsets, segment_length, weight, fin)
         if not on_device:
             out[b] = acc.view(S, channels, length).to(mix.device)

@@ -341,6 +341,15 @@ int HModel::run_deep(HGeo &g, HEncW &e, int C, int Tn, int B, float *x, float *t
             mi_conv_desc gi = base_desc(l.ih[layer], k, layer ? x_o0 : xin, (int64_t)Kin * W, gs);
             gi.plain = 1; gi.epi = MI_EPI_LINEAR; gi.y = x_gx; gi.y_bstride = (int64_t)8 * H * W; gi.y_cstride = W;
             MI_TRY(conv(gi, st));
+            if (prof.on) {         // the LSTM recurrence: W dependent launches timed as one span (bench.py's latency roofline of the mode)
+                const int cls = 101;
+                Profiler::Pending p{cls, prof.get(), prof.get(), (double)W * 2.0 * 8.0 * H * H * N, (double)W * (8.0 * H * H + 8.0 * H * N) * 4.0, W};
+                MI_HIP(hipEventRecord(p.a, st));
+                MI_TRY(launch_lstm_seq(x_gx, l.whhT[layer], N, H, W, layer ? x_o1 : x_o0, x_lstm, st));
+                MI_HIP(hipEventRecord(p.b, st));
+                prof.pending.push_back(p);
+                snprintf(prof.rows[cls].name, sizeof(prof.rows[cls].name), "lstm_step_kernel");
+            } else
             MI_TRY(launch_lstm_seq(x_gx, l.whhT[layer], N, H, W, layer ? x_o1 : x_o0, x_lstm, st));
         }
         MI_TRY(ktab(g, Gather{2 * H, 1, 1, 1, 1, 0, 0, (int64_t)W, W}, l.lin.Kpad, &k));

@@ -65,7 +65,7 @@ struct ProfRow {
 };
 struct Profiler {
     bool on = false;
-    struct Pending { int cls; hipEvent_t a, b; double flops, bytes; };
+    struct Pending { int cls; hipEvent_t a, b; double flops, bytes; long long launches = 1; };
     std::vector<Pending> pending;
     std::vector<hipEvent_t> pool;
     ProfRow rows[128];
@@ -91,7 +91,8 @@ struct WorkspacePtrs {
     // in-projections and lin1 move global -> LDS by DMA
     float *w_tr_ximg[2][2] = {}, *w_tr_x1img[2] = {};
     float *w_yspec = nullptr, *w_ytime = nullptr, *w_yt = nullptr, *w_fr = nullptr;
-    double *w_stats = nullptr, *w_stats_t = nullptr, *w_gram = nullptr, *w_gram2 = nullptr;
+    double *w_stats = nullptr, *w_stats_t = nullptr, *w_gram = nullptr, *w_gram2 = nullptr, *w_gram2_t = nullptr;
+    size_t gram2t_bytes = 0;
     size_t gram2_bytes = 0;      // w_gram2: Gram accumulators of the implicit-GEMM DConv route (rows x slots x HP x HP float64)
     float2 *w_st1 = nullptr, *w_st2 = nullptr, *w_st1_t = nullptr, *w_st2_t = nullptr;
     float2 *w_norm_f = nullptr, *w_denorm_f = nullptr, *w_norm_t = nullptr, *w_denorm_t = nullptr;
@@ -130,6 +131,9 @@ struct Model : WorkspacePtrs {
     float *norm_in_w[2] = {}, *norm_in_b[2] = {}, *pos_emb[2] = {};
     TrLayerW tr[2][5];
 
+    hipStream_t side_st = nullptr;          // the waveform branch's stream (run_core_impl)
+    hipEvent_t ev_main = nullptr, ev_side = nullptr;
+    int side_streams();
     std::shared_ptr<Workspace> ws;   // activation workspace, shared by every handle with the same (device, geometry, max_batch)
 
     ~Model();
@@ -154,7 +158,7 @@ struct Model : WorkspacePtrs {
     int alloc_workspace();
     int fill_workspace(Workspace &w);
     int run_dconv(const DConvW &w, int C, const Geo &g, float *x, float *tmp, float *hidden, double *stats, float2 *st1, float2 *st2,
-                  hipStream_t st);
+                  hipStream_t st, double *gram2 = nullptr, size_t gram2_cap = 0);
     int run_tr_layer(int br, int k, int B, const float *x, const float2 *xstat, const float *other, const float2 *ostat, float *out,
                      float2 *outstat, hipStream_t st, const void *ximg = nullptr, const void *oimg = nullptr, void *outimg = nullptr);
 };

@@ -44,6 +44,18 @@ int Model::upload(const std::vector<T> &h, T **dptr) {
 
 Model::~Model() {
     for (void *p : allocs) (void)hipFree(p);
+    if (side_st) (void)hipStreamDestroy(side_st);
+    if (ev_main) (void)hipEventDestroy(ev_main);
+    if (ev_side) (void)hipEventDestroy(ev_side);
+}
+
+// side stream and the two fork / join events of the two-branch schedule (created on first use)
+int Model::side_streams() {
+    if (side_st) return MI_OK;
+    MI_HIP(hipStreamCreateWithFlags(&side_st, hipStreamNonBlocking));
+    MI_HIP(hipEventCreateWithFlags(&ev_main, hipEventDisableTiming));
+    MI_HIP(hipEventCreateWithFlags(&ev_side, hipEventDisableTiming));
+    return MI_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -66,7 +78,7 @@ int Profiler::end(hipStream_t st) {
         float ms = 0.f;
         MI_HIP(hipEventElapsedTime(&ms, p.a, p.b));
         ProfRow &r = rows[p.cls];
-        r.cls = p.cls; r.launches++; r.ms += ms; r.flops += p.flops; r.bytes += p.bytes;
+        r.cls = p.cls; r.launches += p.launches; r.ms += ms; r.flops += p.flops; r.bytes += p.bytes;
         pool.push_back(p.a); pool.push_back(p.b);
     }
     pending.clear();
@@ -611,6 +623,9 @@ int Model::fill_workspace(Workspace &w) {
     w.gram2_bytes = B * ((size_t)4 << 20);                         // B x 512 rows x 32 x 32 float64 is the largest user
     MI_TRY(dev_alloc((void **)&w.w_gram2, w.gram2_bytes));
     MI_HIP(hipMemset(w.w_gram2, 0, w.gram2_bytes));
+    w.gram2t_bytes = B * ((size_t)1 << 20);                        // the waveform branch's own accumulators (it runs on a side stream)
+    MI_TRY(dev_alloc((void **)&w.w_gram2_t, w.gram2t_bytes));
+    MI_HIP(hipMemset(w.w_gram2_t, 0, w.gram2t_bytes));
     MI_HIP(hipMemset(w.w_stats, 0, w.stats_bytes));      // finalize_stats re-zeroes after each use
     MI_HIP(hipMemset(w.w_stats_t, 0, w.stats_bytes));
     MI_TRY(dev_alloc((void **)&w.w_st1, max_rows * sizeof(float2)));
@@ -642,7 +657,8 @@ static bool debug_sync() {
 // ------------------------------------------------------------------------------------------------
 // DConv residual branch, in place on x[b][C][D1][D2] (uses tmp of the same size and hidden of size/8)
 int Model::run_dconv(const DConvW &w, int C, const Geo &g, float *x, float *tmp, float *hidden, double *stats, float2 *st1,
-                     float2 *st2, hipStream_t st) {
+                     float2 *st2, hipStream_t st, double *gram2, size_t gram2_cap) {
+    if (!gram2) { gram2 = w_gram2; gram2_cap = gram2_bytes; }
     const int h = w.h, hp = round_up(h, 16);
     const int64_t P = (int64_t)g.D1 * g.pitch();
     const int rows = g.row_mode ? g.B * g.D1 : g.B;
@@ -688,10 +704,10 @@ int Model::run_dconv(const DConvW &w, int C, const Geo &g, float *x, float *tmp,
         // GroupNorm + GELU of the hidden tensor in place, and in the same pass the Gram sums from which the second GroupNorm's
         // statistics follow (no statistics-only evaluation of the 2C x h GEMM)
         const int gslots = g.row_mode ? 1 : 8, HP = gram_hp(h);
-        MI_REQUIRE((size_t)rows * gslots * HP * HP * sizeof(double) <= gram2_bytes, "dconv: Gram accumulators need %zu bytes, workspace has %zu",
-                   (size_t)rows * gslots * HP * HP * sizeof(double), gram2_bytes);
-        MI_TRY(launch_gn_gelu_gram(hidden, g.B, h, hp, g.D1, g.D2, g.pitch(), g.row_mode, st1, l.gn1_w, l.gn1_b, w_gram2, gslots, st));
-        MI_TRY(launch_gram_finalize(w_gram2, rows, h, gslots, l.gram_wt, l.gram_ct, l.sum_b, l.sum_bsq, cnt_row, cnt_row * 2 * C, 1e-5f, st2, st));
+        MI_REQUIRE((size_t)rows * gslots * HP * HP * sizeof(double) <= gram2_cap, "dconv: Gram accumulators need %zu bytes, workspace has %zu",
+                   (size_t)rows * gslots * HP * HP * sizeof(double), gram2_cap);
+        MI_TRY(launch_gn_gelu_gram(hidden, g.B, h, hp, g.D1, g.D2, g.pitch(), g.row_mode, st1, l.gn1_w, l.gn1_b, gram2, gslots, st));
+        MI_TRY(launch_gram_finalize(gram2, rows, h, gslots, l.gram_wt, l.gram_ct, l.sum_b, l.sum_bsq, cnt_row, cnt_row * 2 * C, 1e-5f, st2, st));
         mi_conv_desc e = base_desc(l.conv1, l.ktab1, hidden, (int64_t)hp * P, g);
         e.plain = 1;
         e.epi = MI_EPI_GN_GLU; e.stats = nullptr; e.gn_stats = (const float *)st2; e.gn_w = l.gn2_w; e.gn_b = l.gn2_b;
@@ -795,6 +811,7 @@ int Model::run_core(const float *mix, const float *mag, int B, hipStream_t st) {
         MI_HIP(hipMemsetAsync(w_stats_t, 0, ws->stats_bytes, st));
         MI_HIP(hipMemsetAsync(w_gram, 0, ws->gram_bytes, st));
         MI_HIP(hipMemsetAsync(w_gram2, 0, gram2_bytes, st));
+        MI_HIP(hipMemsetAsync(w_gram2_t, 0, gram2t_bytes, st));
         ws->dirty = false;
     }
     const int r = run_core_impl(mix, mag, B, st);
@@ -825,10 +842,30 @@ int Model::forward_core(const float *mix, const float *mag, float *spec_out, flo
 int Model::run_core_impl(const float *mix, const float *mag, int B, hipStream_t st) {
     MI_REQUIRE(B >= 1 && B <= cfg.max_batch, "forward: batch %d outside [1, %d]", B, cfg.max_batch);
     const int Tf = 8 * T, Tt = Lt[4];
+    // The waveform branch runs on a SIDE stream beside the spectral branch on the caller's stream: the two U-Net halves only
+    // meet in the cross-transformer (once per layer: cross-attention reads the other branch's layer input) and in the final sum,
+    // and their kernels -- a third of the spectral branch's size, many of them one or two waves of workgroups -- fill the tails
+    // of each other's launches.  Every buffer the branches write is per branch (statistics slots, Gram accumulators, scratch).
+    static const bool one_stream = getenv("MI_ONE_STREAM") != nullptr;
+    const bool two = !one_stream && !debug_sync() && side_streams() == MI_OK;
+    hipStream_t stt = two ? side_st : st;
+    auto fork = [&]() -> int {              // the side stream waits for everything enqueued on the caller's stream so far
+        if (!two) return MI_OK;
+        MI_HIP(hipEventRecord(ev_main, st));
+        MI_HIP(hipStreamWaitEvent(side_st, ev_main, 0));
+        return MI_OK;
+    };
+    auto join = [&]() -> int {              // the caller's stream waits for everything enqueued on the side stream so far
+        if (!two) return MI_OK;
+        MI_HIP(hipEventRecord(ev_side, side_st));
+        MI_HIP(hipStreamWaitEvent(st, ev_side, 0));
+        return MI_OK;
+    };
+    MI_TRY(fork());
     // ---- input statistics and normalisation (htdemucs.py:545-554) --------------------------------
-    MI_TRY(launch_row_stats(mix, B, (int64_t)2 * SL, (int64_t)2 * SL, w_stats_t, st));
-    MI_TRY(launch_finalize_stats(w_stats_t, B, 2.0 * SL, 1e-5f, 1, w_norm_t, w_denorm_t, st));
-    MI_TRY(launch_row_affine(mix, B, (int64_t)2 * SL, w_norm_t, w_xt0, st));
+    MI_TRY(launch_row_stats(mix, B, (int64_t)2 * SL, (int64_t)2 * SL, w_stats_t, stt));
+    MI_TRY(launch_finalize_stats(w_stats_t, B, 2.0 * SL, 1e-5f, 1, w_norm_t, w_denorm_t, stt));
+    MI_TRY(launch_row_affine(mix, B, (int64_t)2 * SL, w_norm_t, w_xt0, stt));
     MI_STAGE("time normalisation done");
     if (mag) {      // forward_core with a caller-computed spectrogram (htdemucs.py:662-690: `mag` is an INPUT there)
         const int64_t cnt = (int64_t)4 * 2048 * T;
@@ -869,11 +906,11 @@ int Model::run_core_impl(const float *mix, const float *mag, int B, hipStream_t 
             mi_conv_desc d = base_desc(tenc[i].conv, tenc[i].ktab_conv, xt, (int64_t)Cint * Lp[i], gin);
             d.O2 = Lp[i + 1]; d.o2_valid = Lt[i + 1]; d.S2 = 4; d.epi = MI_EPI_LINEAR; d.flags = MI_FLAG_GELU;
             d.y = w_ta; d.y_bstride = C * P; d.y_cstride = P;
-            MI_TRY(conv(d, st));
-            MI_TRY(run_dconv(tenc[i].dconv, C, go, w_ta, w_tb, w_th, w_stats_t, w_st1_t, w_st2_t, st));
+            MI_TRY(conv(d, stt));
+            MI_TRY(run_dconv(tenc[i].dconv, C, go, w_ta, w_tb, w_th, w_stats_t, w_st1_t, w_st2_t, stt, w_gram2_t, gram2t_bytes));
             mi_conv_desc r = base_desc(tenc[i].rewrite, tenc[i].ktab_rw, w_ta, C * P, go);
             r.plain = 1; r.epi = MI_EPI_GLU; r.y = w_skip_t[i]; r.y_bstride = C * P; r.y_cstride = P;
-            MI_TRY(conv(r, st));
+            MI_TRY(conv(r, stt));
             xt = w_skip_t[i];
             MI_STAGE("tenc layer done");
         }
@@ -886,20 +923,25 @@ int Model::run_core_impl(const float *mix, const float *mag, int B, hipStream_t 
     for (int br = 0; br < 2; ++br) {
         const int P = br ? Tt : Tf;
         const Geo g{B, 1, P, 0};
+        hipStream_t sb = br ? stt : st;
         mi_conv_desc d = base_desc(chan[br], chan_ktab[br], br ? xt : xf, (int64_t)384 * P, g);
         d.plain = 1; d.epi = MI_EPI_LINEAR; d.y = w_tr_x1[br]; d.y_bstride = (int64_t)512 * P; d.y_cstride = P;
-        MI_TRY(conv(d, st));
+        MI_TRY(conv(d, sb));
         MI_TRY(launch_layernorm_cf(w_tr_x1[br], B, 512, P, norm_in_w[br], norm_in_b[br], pos_emb[br], w_tr_x[br][0],
-                                   w_tr_stat[br][0], st, in_img ? w_tr_ximg[br][0] : nullptr, (int64_t)B * P, cfg.dtype));
+                                   w_tr_stat[br][0], sb, in_img ? w_tr_ximg[br][0] : nullptr, (int64_t)B * P, cfg.dtype));
     }
     MI_STAGE("upsample + norm_in done");
     for (int k = 0; k < 5; ++k) {
         const float *f_in = w_tr_x[0][cur[0]], *t_in = w_tr_x[1][cur[1]];
         const float2 *f_st = w_tr_stat[0][cur[0]], *t_st = w_tr_stat[1][cur[1]];
         const void *f_img = in_img ? w_tr_ximg[0][cur[0]] : nullptr, *t_img = in_img ? w_tr_ximg[1][cur[1]] : nullptr;
+        // both branches' layer inputs are complete on BOTH streams (a cross layer reads the other branch's input, and a layer
+        // overwrites the buffer the other branch read two layers ago)
+        MI_TRY(join());
+        MI_TRY(fork());
         MI_TRY(run_tr_layer(0, k, B, f_in, f_st, t_in, t_st, w_tr_x[0][cur[0] ^ 1], w_tr_stat[0][cur[0] ^ 1], st, f_img, t_img,
                             w_tr_ximg[0][cur[0] ^ 1]));
-        MI_TRY(run_tr_layer(1, k, B, t_in, t_st, f_in, f_st, w_tr_x[1][cur[1] ^ 1], w_tr_stat[1][cur[1] ^ 1], st, t_img, f_img,
+        MI_TRY(run_tr_layer(1, k, B, t_in, t_st, f_in, f_st, w_tr_x[1][cur[1] ^ 1], w_tr_stat[1][cur[1] ^ 1], stt, t_img, f_img,
                             w_tr_ximg[1][cur[1] ^ 1]));
         cur[0] ^= 1; cur[1] ^= 1;
         MI_STAGE("transformer layer done");
@@ -911,7 +953,7 @@ int Model::run_core_impl(const float *mix, const float *mag, int B, hipStream_t 
         mi_conv_desc d = base_desc(chan[2 + br], chan_ktab[2 + br], w_tr_x[br][cur[br]], (int64_t)512 * P, g);
         d.plain = 1; d.epi = MI_EPI_LINEAR; d.flags = MI_FLAG_RES; d.res = br ? w_skip_t[3] : w_skip[3];
         d.y = br ? dtin : din; d.y_bstride = (int64_t)384 * P; d.y_cstride = P;
-        MI_TRY(conv(d, st));
+        MI_TRY(conv(d, br ? stt : st));
     }
     // ---- decoders ----------------------------------------------------------------------------------
     for (int j = 0; j < 4; ++j) {
@@ -939,17 +981,18 @@ int Model::run_core_impl(const float *mix, const float *mag, int B, hipStream_t 
             const Geo g{B, 1, Lv, 0, L};
             mi_conv_desc r = base_desc(tdec[j].rewrite, tdec[j].ktab_rw, dtin, (int64_t)C * L, g);
             r.epi = MI_EPI_GLU; r.y = w_ta; r.y_bstride = (int64_t)C * L; r.y_cstride = L;
-            MI_TRY(conv(r, st));
-            MI_TRY(run_dconv(tdec[j].dconv, C, g, w_ta, w_tb, w_th, w_stats_t, w_st1_t, w_st2_t, st));
+            MI_TRY(conv(r, stt));
+            MI_TRY(run_dconv(tdec[j].dconv, C, g, w_ta, w_tb, w_th, w_stats_t, w_st1_t, w_st2_t, stt, w_gram2_t, gram2t_bytes));
             const int Cout = last ? 2 * S : kCh[2 - j];
             mi_conv_desc t = base_desc(tdec[j].convtr, tdec[j].ktab_tr, w_ta, (int64_t)C * L, g);
             t.O2 = Lv + 1; t.o2_valid = 0; t.epi = MI_EPI_CONVTR; t.out_len = Lout;     // q = 0 .. Lv, scattered to 4q + r - 2
             t.y_cstride = Lpo; t.y_bstride = (int64_t)Cout * Lpo;
             if (last) t.y = w_ytime;
             else { t.flags |= MI_FLAG_GELU | MI_FLAG_RES; t.res = w_skip_t[2 - j]; t.y = dtin; }
-            MI_TRY(conv(t, st));
+            MI_TRY(conv(t, stt));
         }
     }
+    MI_TRY(join());                         // the waveform decoder's output is complete on the caller's stream
     MI_STAGE("decoders done");
     return MI_OK;
 }

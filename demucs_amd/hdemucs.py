@@ -161,6 +161,21 @@ class HDemucs:
         lib = _lib.load()
         return sum(int(lib.mi_hmodel_device_bytes(C.c_void_p(h))) for (dev, _aux), (h, _) in self._handles.items() if dev == self._device)
 
+    def profile_begin(self) -> None:
+        """Per-kernel-class HIP-event timing of the MAIN engine handle from here to profile_end (bench.py)."""
+        h = self._handles[(self._device, False)][0]
+        _lib.check(_lib.load().mi_profile_begin(C.c_void_p(h)), "mi_profile_begin")
+
+    def profile_end(self):
+        rows = (_lib.MiProfileRow * 128)()
+        n = C.c_int32()
+        h = self._handles[(self._device, False)][0]
+        with torch.cuda.device(self._device):
+            _lib.check(_lib.load().mi_profile_end(C.c_void_p(h), rows, 128, C.byref(n), C.c_void_p(_lib.current_stream_ptr())),
+                       "mi_profile_end")
+        return [dict(name=rows[i].name.decode(), launches=rows[i].launches, ms=rows[i].ms, flops=rows[i].flops, bytes=rows[i].bytes)
+                for i in range(n.value)]
+
     def tap(self, name: str, batch: int) -> torch.Tensor:
         """Copy of an internal activation of the last forward (parity tests), shape (batch, numel)."""
         lib, n = _lib.load(), C.c_int64()

@@ -6,8 +6,11 @@ into roofline.traffic).
     python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/round1_traffic.json
 
 gfx950 corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE and WRITE_SIZE are in KiB;
-FETCH_SIZE reports exactly half of the bytes of wide (16 B/lane) coalesced reads, which is how the
-GEMM / attention kernels load, so reads are doubled; WRITE_SIZE is taken as is.
+FETCH_SIZE reports exactly half of the bytes of wide (16 B/lane) coalesced reads -- the LDS-DMA
+GEMMs, the attention kernels, the float4 / float2 streaming kernels -- so their reads are doubled;
+WRITE_SIZE is taken as is.  The guide states the factor for 16 B/lane streaming reads only: for the
+table-driven gather loops (dword loads) it is uncalibrated, so those classes carry `read_access:
+"dword gather"` and both bounds (`read_bytes_x1`, the raw counter, and the doubled figure).
 """
 import collections
 import csv
@@ -35,9 +38,13 @@ def klass(name):
     m = re.search(r"conv_gemm_half_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (true|false)>", name)
     if m:
         ht, wm, wn, tm, tn, epi, _, plain = m.groups()
-        return f"conv_gemm_{'bf16' if ht == '1' else 'f16'}<{EPI[int(epi)]},tile{TILE[(int(wm), int(wn), int(tm), int(tn))]}{',1x1' if plain == 'true' else ''}>"
+        tile = 128 if (wm, wn, tm, tn) == ("2", "2", "4", "2") else TILE[(int(wm), int(wn), int(tm), int(tn))]     # 256-row tile: bench class tile128
+        return f"conv_gemm_{'bf16' if ht == '1' else 'f16'}<{EPI[int(epi)]},tile{tile}{',1x1' if plain == 'true' else ''}>"
+    m = re.search(r"conv_gemm_half_img(?:256)?_kernel<(\d+)", name)      # operand-image inputs (LDS-DMA): the transformer's linear layers
+    if m:
+        return f"conv_gemm_{'bf16' if m.group(1) == '1' else 'f16'}<linear,tile128,1x1>"
     # kernels named in north_star's HBM-bound list: STFT (K1), iSTFT (K15), the fused DConv kernels, the scheduler's OLA
-    for k in ("attention_half_kernel", "attention_kernel", "dconv_row_kernel", "dconv_t_conv3_kernel", "dconv_t_gram_kernel", "dconv_t_out_kernel",
+    for k in ("attention_heads_kernel", "attention_half_kernel", "attention_kernel", "dconv_row_kernel", "dconv_t_conv3_kernel", "dconv_t_gram_kernel", "dconv_t_out_kernel",
               "istft_frames_kernel", "istft_ola_kernel", "stft_frames_kernel", "cac_transpose_kernel", "spec_transpose_kernel",
               "ola_accumulate_kernel", "ola_finish_kernel", "segments_gather_kernel", "token_tile_kernel", "row_stats_kernel", "gn_gelu_kernel"):
         if k in name:
@@ -67,9 +74,12 @@ def main():
         wn, ws = w.get(k, [0, 0.0])
         rd = 2.0 * fs * 1024 / n
         wr = ws * 1024 / max(1, wn)
+        gather = k.startswith("conv_gemm") and not k.endswith(",1x1>")      # table-driven dword gathers: the x2 factor is uncalibrated
         res[k] = {"launches_sampled": n, "read_bytes_per_launch": round(rd), "write_bytes_per_launch": round(wr),
-                  "traffic_bytes_per_launch": round(rd + wr),
-                  "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, KiB units, FETCH_SIZE x2 (gfx950 wide-read correction)"}
+                  "traffic_bytes_per_launch": round(rd + wr), "read_access": "dword gather" if gather else "wide (>= 8 B per lane)",
+                  "read_bytes_x1": round(rd / 2),
+                  "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, KiB units, FETCH_SIZE x2 (gfx950 wide-read correction"
+                            + ("; uncalibrated for this class's dword gathers: the true read figure lies between read_bytes_x1 and read_bytes_per_launch)" if gather else ")")}
     json.dump(res, open(dst, "w"), indent=1)
     for k, v in res.items():
         print(f"{k:40s} {v['traffic_bytes_per_launch'] / 1e6:9.1f} MB/launch  (read {v['read_bytes_per_launch'] / 1e6:.1f}, write {v['write_bytes_per_launch'] / 1e6:.1f})")
