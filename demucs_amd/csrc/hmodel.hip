@@ -225,6 +225,9 @@ int HModel::hinit(const mi_config &c, const mi_tensor_desc *weights, size_t n) {
     gram2_bytes = B * ((size_t)4 << 20);                  // Model::run_dconv's Gram accumulators: B x 512 rows x 32 x 32 float64 at layer 0
     MI_TRY(halloc((void **)&w_gram2, gram2_bytes));
     MI_HIP(hipMemset(w_gram2, 0, gram2_bytes));
+    gram2t_bytes = B * ((size_t)2 << 20);                 // the waveform branch's own accumulators: it runs on the side stream
+    MI_TRY(halloc((void **)&w_gram2_t, gram2t_bytes));
+    MI_HIP(hipMemset(w_gram2_t, 0, gram2t_bytes));
     MI_TRY(halloc((void **)&x_st1, max_rows * sizeof(float2))); MI_TRY(halloc((void **)&x_st2, max_rows * sizeof(float2)));
     MI_TRY(halloc((void **)&x_st1t, max_rows * sizeof(float2))); MI_TRY(halloc((void **)&x_st2t, max_rows * sizeof(float2)));
     MI_TRY(halloc((void **)&x_nf, B * sizeof(float2))); MI_TRY(halloc((void **)&x_df, B * sizeof(float2)));
@@ -388,6 +391,7 @@ int HModel::hforward(const float *mix, float *out, int B, int L, hipStream_t st)
         MI_HIP(hipMemsetAsync(x_stats, 0, x_stats_bytes, st));
         MI_HIP(hipMemsetAsync(x_stats_t, 0, x_stats_bytes, st));
         MI_HIP(hipMemsetAsync(w_gram2, 0, gram2_bytes, st));
+        MI_HIP(hipMemsetAsync(w_gram2_t, 0, gram2t_bytes, st));
         x_dirty = false;
     }
     const int r = hforward_impl(mix, out, B, L, st);
@@ -407,10 +411,31 @@ int HModel::hforward_impl(const float *mix, float *out, int B, int L, hipStream_
     const int *Lt = g.Lt, *Lp = g.Lp;
     const mi_ktab_entry *k;
     taps.clear();
+    // MI_H_TWO_STREAMS=1: the waveform branch of layers 0-3 (and of decoder layers 2-5) on the side stream beside the spectral
+    // branch, as in Model::run_core_impl.  OFF by default for this architecture: measured 58.5 ms against 53.3 ms for the
+    // 3-minute track -- the forward is paced by the 1 600 DEPENDENT LSTM step launches of layers 4 / 5, the track's tail chunk
+    // already runs beside the batched forward on its own engine and stream, and more concurrent kernels only lengthen every
+    // step of that chain (5.5-7 -> 8.3 us per launch).
+    static const bool h_two = getenv("MI_H_TWO_STREAMS") != nullptr;
+    const bool two = h_two && side_streams() == MI_OK;
+    hipStream_t stt = two ? side_st : st;
+    auto fork = [&]() -> int {
+        if (!two) return MI_OK;
+        MI_HIP(hipEventRecord(ev_main, st));
+        MI_HIP(hipStreamWaitEvent(side_st, ev_main, 0));
+        return MI_OK;
+    };
+    auto join = [&]() -> int {
+        if (!two) return MI_OK;
+        MI_HIP(hipEventRecord(ev_side, side_st));
+        MI_HIP(hipStreamWaitEvent(st, ev_side, 0));
+        return MI_OK;
+    };
+    MI_TRY(fork());
     // ---- input statistics, normalisation, STFT (hdemucs.py:693-712) ----------------------------------------------
-    MI_TRY(launch_row_stats(mix, B, (int64_t)2 * L, (int64_t)2 * L, x_stats_t, st));
-    MI_TRY(launch_finalize_stats(x_stats_t, B, 2.0 * L, 1e-5f, 1, x_nt, x_dt, st));
-    MI_TRY(launch_row_affine_pitch(mix, B, 2, L, Lp[0], x_nt, x_t0, st));
+    MI_TRY(launch_row_stats(mix, B, (int64_t)2 * L, (int64_t)2 * L, x_stats_t, stt));
+    MI_TRY(launch_finalize_stats(x_stats_t, B, 2.0 * L, 1e-5f, 1, x_nt, x_dt, stt));
+    MI_TRY(launch_row_affine_pitch(mix, B, 2, L, Lp[0], x_nt, x_t0, stt));
     MI_TRY(launch_stft_frames(mix, B, L, fft, x_zt, x_stats, st));
     MI_TRY(launch_finalize_stats(x_stats, B, 4.0 * 2048 * T, 1e-5f, 1, x_nf, x_df, st));
     MI_TRY(launch_cac_transpose(x_zt, B, T, x_nf, x_0, st, Tp));
@@ -425,12 +450,12 @@ int HModel::hforward_impl(const float *mix, float *out, int B, int L, hipStream_
             mi_conv_desc d = base_desc(htenc[i].conv, k, xt, (int64_t)Cint * Lp[i], gin);
             d.O2 = Lp[i + 1]; d.o2_valid = Lt[i + 1]; d.S2 = 4; d.epi = MI_EPI_LINEAR; d.flags = MI_FLAG_GELU;
             d.y = x_ta; d.y_bstride = C * P; d.y_cstride = P;
-            MI_TRY(conv(d, st));
-            MI_TRY(run_dconv(g.tenc_dconv[i], C, go, x_ta, x_tb, x_th, x_stats_t, x_st1t, x_st2t, st));
+            MI_TRY(conv(d, stt));
+            MI_TRY(run_dconv(g.tenc_dconv[i], C, go, x_ta, x_tb, x_th, x_stats_t, x_st1t, x_st2t, stt, w_gram2_t, gram2t_bytes));
             MI_TRY(ktab(g, Gather{C, 1, 1, 1, 1, 0, 0, P, (int)P}, htenc[i].rewrite.Kpad, &k));
             mi_conv_desc r = base_desc(htenc[i].rewrite, k, x_ta, C * P, go);
             r.plain = 1; r.epi = MI_EPI_GLU; r.y = x_skip_t[i]; r.y_bstride = C * P; r.y_cstride = P;
-            MI_TRY(conv(r, st));
+            MI_TRY(conv(r, stt));
             xt = x_skip_t[i];
             taps["tenc" + std::to_string(i)] = {x_skip_t[i], C * P};
         }
@@ -457,7 +482,8 @@ int HModel::hforward_impl(const float *mix, float *out, int B, int L, hipStream_
         MI_TRY(ktab(g, Gather{384, 1, 8, 1, 1, 0, 2, (int64_t)Lp[4], Lp[4]}, htenc[4].conv.Kpad, &k));
         mi_conv_desc d = base_desc(htenc[4].conv, k, xt, (int64_t)384 * Lp[4], Geo{B, 1, Lt[4], 0, Lp[4]});
         d.O2 = T; d.o2_valid = 0; d.S2 = 4; d.epi = MI_EPI_LINEAR; d.y = x_inject; d.y_bstride = (int64_t)768 * T; d.y_cstride = T;
-        MI_TRY(conv(d, st));
+        MI_TRY(conv(d, stt));
+        MI_TRY(join());                            // the injection and everything the waveform encoder wrote (its skips) are complete
         taps["tenc4"] = {x_inject, (int64_t)768 * T};
         MI_TRY(ktab(g, Gather{384, 8, 1, 1, 1, 0, 0, (int64_t)8 * Tp, Tp}, henc[4].conv.Kpad, &k));
         mi_conv_desc e = base_desc(henc[4].conv, k, xf, (int64_t)384 * 8 * Tp, Geo{B, 8, T, 1, Tp});
@@ -530,6 +556,7 @@ int HModel::hforward_impl(const float *mix, float *out, int B, int L, hipStream_
         taps["tdec0+skip"] = {x_tdec[0], (int64_t)384 * Lp[4]};
     }
     // ---- decoder.2-5 / tdecoder.1-4: rewrite 3x3 (k 3) + GLU -> ConvTranspose (+ GELU + next skip) -------------------------
+    MI_TRY(fork());
     for (int j = 2; j < 6; ++j) {
         const int i = 5 - j, C = hCh[i], Fr = hFr[i + 1];
         const bool last = j == 5;
@@ -555,18 +582,19 @@ int HModel::hforward_impl(const float *mix, float *out, int B, int L, hipStream_
             MI_TRY(ktab(g, Gather{C, 1, 3, 1, 1, 0, 1, (int64_t)Lq, Lq}, htdec[j - 1].rewrite.Kpad, &k));
             mi_conv_desc r = base_desc(htdec[j - 1].rewrite, k, x_tdec[j - 2], (int64_t)C * Lq, gg);
             r.epi = MI_EPI_GLU; r.y = x_ta; r.y_bstride = (int64_t)C * Lq; r.y_cstride = Lq;
-            MI_TRY(conv(r, st));
+            MI_TRY(conv(r, stt));
             const int Cout = last ? 2 * S : hCh[i - 1];
             MI_TRY(ktab(g, Gather{C, 1, 2, 1, -1, 0, 0, (int64_t)Lq, Lq}, htdec[j - 1].convtr.Kpad, &k));
             mi_conv_desc t = base_desc(htdec[j - 1].convtr, k, x_ta, (int64_t)C * Lq, gg);
             t.O2 = Lv + 1; t.o2_valid = 0; t.epi = MI_EPI_CONVTR; t.out_len = Lout;
             t.y_cstride = Lpo; t.y_bstride = (int64_t)Cout * Lpo; t.y = x_tdec[j - 1];
             if (!last) { t.flags |= MI_FLAG_GELU | MI_FLAG_RES; t.res = x_skip_t[i - 1]; }
-            MI_TRY(conv(t, st));
+            MI_TRY(conv(t, stt));
             taps[std::string("tdec") + std::to_string(j - 1) + (last ? "" : "+skip")] = {x_tdec[j - 1], t.y_bstride};
         }
     }
     // ---- de-normalise, iSTFT, add the time branch (hdemucs.py:770-793) -------------------------------------------------
+    MI_TRY(join());
     return launch_istft(x_dec[5], B, S, L, x_df, x_tdec[4], x_dt, fft, x_yt, x_fr, out, st, Lp[0], Tp);
 }
 
