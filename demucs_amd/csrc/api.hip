@@ -153,6 +153,12 @@ int mi_hmodel_tap(void *handle, const char *name, float *dst_dev, int32_t B, int
 
 int64_t mi_hmodel_device_bytes(void *handle) { return handle ? ((HModel *)handle)->device_bytes + ((HModel *)handle)->hws_bytes : 0; }
 
+int mi_set_two_streams(int32_t enabled) {
+    const int old = g_two_streams;
+    g_two_streams = enabled ? 1 : 0;
+    return old;
+}
+
 int mi_profile_begin(void *handle) {
     if (!handle) return set_error(MI_EINVAL, "mi_profile_begin: null handle");
     ((Model *)handle)->prof.begin();

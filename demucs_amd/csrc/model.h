@@ -10,6 +10,7 @@
 
 namespace mi {
 
+extern int g_two_streams;      // model.hip: 1 = waveform branch on a side stream (default), 0 = everything on the caller's stream
 struct WeightTable;
 struct Gather;
 struct Geo;

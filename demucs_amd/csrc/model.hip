@@ -49,6 +49,10 @@ Model::~Model() {
     if (ev_side) (void)hipEventDestroy(ev_side);
 }
 
+// run-time switch of the two-branch schedule (mi_set_two_streams: bench.py times its per-kernel roofline pass with one kernel
+// on the GPU at a time)
+int g_two_streams = 1;
+
 // side stream and the two fork / join events of the two-branch schedule (created on first use)
 int Model::side_streams() {
     if (side_st) return MI_OK;
@@ -847,7 +851,7 @@ int Model::run_core_impl(const float *mix, const float *mag, int B, hipStream_t 
     // and their kernels -- a third of the spectral branch's size, many of them one or two waves of workgroups -- fill the tails
     // of each other's launches.  Every buffer the branches write is per branch (statistics slots, Gram accumulators, scratch).
     static const bool one_stream = getenv("MI_ONE_STREAM") != nullptr;
-    const bool two = !one_stream && !debug_sync() && side_streams() == MI_OK;
+    const bool two = !one_stream && g_two_streams && !debug_sync() && side_streams() == MI_OK;
     hipStream_t stt = two ? side_st : st;
     auto fork = [&]() -> int {              // the side stream waits for everything enqueued on the caller's stream so far
         if (!two) return MI_OK;

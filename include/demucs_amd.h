@@ -105,6 +105,10 @@ typedef struct mi_profile_row {
     int64_t launches;
     double ms, flops, bytes;
 } mi_profile_row;
+/* mi_set_two_streams: the htdemucs engine runs the waveform branch of a forward on a side stream beside the spectral branch
+ *   (enabled = 1, the default: results are bit-identical either way); 0 keeps every launch on the caller's stream, one kernel on
+ *   the GPU at a time -- what a per-kernel timing wants.  Returns the previous setting.  Process-wide. */
+int mi_set_two_streams(int32_t enabled);
 int mi_profile_begin(void *handle);
 int mi_profile_end(void *handle, mi_profile_row *rows, int32_t max_rows, int32_t *n_rows, void *stream);
 
