@@ -79,6 +79,8 @@ def main():
     ap.add_argument("--no-host-leg", action="store_true")
     ap.add_argument("--no-fixed-leg", action="store_true")
     ap.add_argument("--no-modes-leg", action="store_true")
+    ap.add_argument("--no-iso-pass", action="store_true", help="skip the one-kernel-at-a-time passes behind the timed region (profiling "
+                    "the default two-stream schedule alone); the roofline then quotes the timed region's own, overlapping, durations")
     ap.add_argument("--force-dist", action="store_true", help="run the N > 1 branch (RCCL process group, sharded apply_model with its "
                     "collectives, max-over-ranks all_reduce) whatever WORLD_SIZE is: rehearses the multi-GPU code on one GPU")
     args = ap.parse_args()
@@ -155,14 +157,16 @@ def main():
     # figures are kept as roofline.in_timed_region).  What the kernel itself reaches is timed right after, on the same inputs,
     # with one kernel on the GPU at a time (mi_set_two_streams(0)): same HIP events on the launch stream.
     from demucs_amd import _lib as _L
-    old_two = _L.load().mi_set_two_streams(0)
-    iso_steps = max(1, min(args.steps, 3))
-    model.profile_begin()
-    for _ in range(iso_steps):
-        step(mix)
-    torch.cuda.synchronize(dev)
-    rows = model.profile_end()
-    _L.load().mi_set_two_streams(old_two)
+    iso_steps = 0 if args.no_iso_pass else max(1, min(args.steps, 3))
+    rows = rows_timed
+    if iso_steps:
+        old_two = _L.load().mi_set_two_streams(0)
+        model.profile_begin()
+        for _ in range(iso_steps):
+            step(mix)
+        torch.cuda.synchronize(dev)
+        rows = model.profile_end()
+        _L.load().mi_set_two_streams(old_two)
     if multi:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -221,9 +225,10 @@ def main():
                                        if multi else "one GPU")},
             "roofline": {"bound": bound, "kernel": dom["name"], "achieved": round(achieved, 2), "peak": peak,
                          "unit": unit, "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
-                         "measured": f"HIP events on the launch stream over {iso_steps} passes of the same workload run right after the timed "
-                                     "region with ONE kernel on the GPU at a time (mi_set_two_streams(0)); agrees with "
-                                     "profiles/round3_f32_one_stream_kernel_stats.csv",
+                         "measured": (f"HIP events on the launch stream over {iso_steps} passes of the same workload run right after the timed "
+                                      "region with ONE kernel on the GPU at a time (mi_set_two_streams(0)); agrees with "
+                                      "profiles/round3_f32_one_stream_kernel_stats.csv") if iso_steps else
+                                     "HIP events on the launch streams over the timed region itself (--no-iso-pass: durations of the two streams overlap)",
                          "in_timed_region": timed_roof,
                          "pipe": ("bf16 MFMA, 6 products per fp32 MAC (exact 3-term operand split, fp32 accumulate)" if x6
                                   else f"{pipe} MFMA" if bound == "mfma" else "HBM"),
@@ -231,7 +236,8 @@ def main():
                          "algorithmic_flops_per_launch": round(dom["flops"] / dom["launches"]),
                          "launches": dom["launches"], "avg_launch_ms": round(dom_ms, 4),
                          "share_of_instrumented_time": round(dom["ms"] / total_ms, 3)},
-            "kernels_note": f"per-class totals of the {iso_steps} one-kernel-at-a-time passes (see roofline.measured)",
+            "kernels_note": f"per-class totals of the {iso_steps or args.steps} passes behind roofline.measured",
+            "kernels_steps": iso_steps or args.steps,
             "kernels": [{"name": r["name"], "launches": r["launches"], "ms": round(r["ms"], 3),
                          "tflops": round(r["flops"] / (r["ms"] * 1e-3) / 1e12, 2),
                          "gbps": round(r["bytes"] / (r["ms"] * 1e-3) / 1e9, 1)} for r in sorted(rows, key=lambda r: -r["ms"])],

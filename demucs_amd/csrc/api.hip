@@ -292,6 +292,11 @@ int mi_conv_pack_split(const float *wt_dev, int32_t Kpad, int32_t Mpad, int32_t 
     return launch_pack_split(wt_dev, Kpad, Mpad, tile_m, wx_dev, (hipStream_t)stream);
 }
 
+int mi_conv_pack_tap(const float *wt_dev, int32_t Mpad, int32_t Cin, int32_t ntaps, int32_t dtype, void *wtap_dev, void *stream) {
+    MI_REQUIRE(wt_dev && wtap_dev && Mpad > 0 && Cin > 0 && ntaps > 0, "mi_conv_pack_tap: bad argument");
+    return launch_pack_tap(wt_dev, Mpad, Cin, ntaps, dtype, wtap_dev, (hipStream_t)stream);
+}
+
 int mi_conv_pack_half(const float *wt_dev, int32_t Kpad, int32_t Mpad, int32_t dtype, void *wh_dev, void *stream) {
     MI_REQUIRE(wt_dev && wh_dev && Kpad > 0 && Mpad > 0, "mi_conv_pack_half: bad argument");
     return launch_pack_half(wt_dev, Kpad, Mpad, dtype, wh_dev, (hipStream_t)stream);

@@ -37,6 +37,8 @@ enum mi_epilogue {
  * token-major tensors  yh[row / 512][b][head = (row / 64) % 8][token (pitch yh_n)][row % 64]  -- the operands of
  * attention_heads.hip (Q, K, V are consumed by nothing else: no float32 copy is written) */
 #define MI_FLAG_HEADS 128
+/* MI_FLAG_IMG on a CONVTR epilogue (half modes): the scattered result goes to `yh` as the operand image
+ * [Cout / 8][yh_n positions][8] of the NEXT layer's k x k conv (position = b * y_cstride + scattered index); y is not written */
 
 typedef struct mi_ktab_entry {
     int32_t off; /* element offset added to the column base: ci*chan_stride + d1*D2 + d2 */
@@ -95,6 +97,10 @@ typedef struct mi_conv_desc {
     int64_t xh_n;           /* its column count                                                                               */
     void *yh;               /* MI_FLAG_IMG: the OUTPUT image (M % 8 == 0); y is not written                                      */
     int64_t yh_n;
+    /* k x k stride-1 conv on an operand-image input (gemm_tap.hip): the weights with k ordered (channel octet, tap, channel % 8)
+       (mi_conv_pack_tap) and the kernel geometry; xh must be set, x / ktab are ignored */
+    const void *wtap;
+    int32_t ntaps, tap_k2, tap_pad1, tap_pad2; /* K1 * K2 taps, K2 columns per kernel row, padding along d1 / d2                  */
 } mi_conv_desc;
 
 #ifdef __cplusplus

@@ -392,9 +392,13 @@ int launch_conv(const mi_conv_desc &din, hipStream_t st) {
     const int64_t P = (int64_t)d.O1 * d.O2;
     const bool plain = d.plain && d.K == d.Kpad && P % 4 == 0 && d.x_bstride % 4 == 0 && ((uintptr_t)d.x & 15) == 0 &&
                        d.S1 == 1 && d.S2 == 1 && d.D1 == d.O1 && (d.x_ld ? d.x_ld : d.D2) == d.O2;
-    MI_REQUIRE(!(d.flags & MI_FLAG_IMG) || (d.half && d.yh && d.epi == MI_EPI_LINEAR && d.M % 8 == 0 && d.yh_n >= (int64_t)d.B * P &&
-                                            ((uintptr_t)d.yh & 15) == 0),
+    MI_REQUIRE(!(d.flags & MI_FLAG_IMG) || d.epi == MI_EPI_CONVTR ||
+               (d.half && d.yh && d.epi == MI_EPI_LINEAR && d.M % 8 == 0 && d.yh_n >= (int64_t)d.B * P && ((uintptr_t)d.yh & 15) == 0),
                "conv: MI_FLAG_IMG needs a half-precision LINEAR layer with M %% 8 == 0 and an aligned output image of >= B * P columns");
+    MI_REQUIRE(!(d.flags & MI_FLAG_IMG) || d.epi != MI_EPI_CONVTR ||
+               (d.half && d.yh && d.yh_n >= (int64_t)d.B * d.y_cstride && ((uintptr_t)d.yh & 15) == 0),
+               "conv: MI_FLAG_IMG on a transposed conv needs a half mode and an output image of >= B * y_cstride positions");
+    if (d.wtap) { MI_REQUIRE(d.half && d.xh, "conv: tap-ordered weights need a half mode and an operand-image input"); return launch_conv_tap(d, tile, st); }
     MI_REQUIRE(!(d.flags & MI_FLAG_HEADS) || (d.half && d.yh && d.epi == MI_EPI_LINEAR && d.M % 512 == 0 && d.O1 == 1 && d.yh_n >= d.O2 &&
                                               ((uintptr_t)d.yh & 15) == 0 && !(d.flags & MI_FLAG_IMG)),
                "conv: MI_FLAG_HEADS needs a half-precision LINEAR layer on tokens (O1 = 1) with M %% 512 == 0 and an aligned output");

@@ -519,6 +519,7 @@ static int launch_conv_half_t(const mi_conv_desc &d, int tile, bool plain, hipSt
             MI_LINEAR(0);
             MI_LINEAR(MI_FLAG_GELU);
             MI_LINEAR(MI_FLAG_RES);
+            MI_LINEAR(MI_FLAG_RES | MI_FLAG_IMG);
             MI_LINEAR(MI_FLAG_SCALE | MI_FLAG_RES);
             MI_LINEAR(MI_FLAG_LN);
             MI_LINEAR(MI_FLAG_LN | MI_FLAG_GELU);

@@ -170,6 +170,13 @@ __device__ __forceinline__ void conv_epilogue(const mi_conv_desc &d, f32x16 (&ac
                     const size_t pos = (d.flags & MI_FLAG_TR_FREQ) ? (size_t)o * d.O2 + c.o2 : (size_t)o;
                     const size_t idx = ok ? (size_t)c.b * d.y_bstride + (size_t)co * d.y_cstride + pos : 0;
                     if (d.flags & MI_FLAG_RES) v += d.res[idx];
+                    if (d.flags & MI_FLAG_IMG) {
+                        // the only reader is the next layer's k x k conv (gemm_tap.hip): 16-bit, [co / 8][position][8]
+                        unsigned short *dst = reinterpret_cast<unsigned short *>(d.yh) +
+                                              (((size_t)(co >> 3) * d.yh_n + (size_t)c.b * d.y_cstride + pos) * 8 + (co & 7));
+                        if (ok) *dst = (unsigned short)(pack_half2(d.half, v, 0.f) & 0xffffu);
+                        continue;
+                    }
                     *(ok ? d.y + idx : sink) = v;
                 }
             }

@@ -88,6 +88,10 @@ int launch_pack_split(const float *wt, int Kpad, int Mpad, int tile_m, void *wx,
 // gemm_half.hip: bf16 / fp16 operand main loop (mi_config.dtype)
 int launch_conv_half(const mi_conv_desc &d, int tile, bool plain, hipStream_t st);
 int launch_pack_half(const float *wt, int Kpad, int Mpad, int dtype, void *wh, hipStream_t st);
+// gemm_tap.hip: k x k stride-1 convs on operand-image inputs (tap-minor K order), half modes
+int conv_tap_pairs_pad(int Cin, int ntaps);
+int launch_pack_tap(const float *wt, int Mpad, int Cin, int ntaps, int dtype, void *out, hipStream_t st);
+int launch_conv_tap(const mi_conv_desc &d, int tile, hipStream_t st);
 
 // hkernels.hip: the Hybrid Demucs v3 (hdemucs_mmi) path's own kernels
 int launch_row_affine_pitch(const float *x, int B, int C, int L, int out_pitch, const float2 *norm, float *y, hipStream_t st);

@@ -19,6 +19,8 @@ struct PackedConv {
     float *wt = nullptr, *bias = nullptr;
     void *wx = nullptr;            // split-bf16 tile image of wt (gemm_x6.hip) when the tile has that main loop
     void *wh = nullptr;            // bf16 / fp16 operand image of wt (gemm_half.hip) in the reduced-precision modes
+    void *wtap = nullptr;          // ... and, for k x k convs fed by an operand image, the tap-ordered image (gemm_tap.hip)
+    int ntaps = 0;
     int M = 0, Mpad = 0, K = 0, Kpad = 0, tile = 0, half = 0;
 };
 
@@ -149,7 +151,8 @@ struct Model : WorkspacePtrs {
     template <typename T> int upload(const std::vector<T> &h, T **dptr);
     int pack_split(PackedConv *pc);
     int pack_half(PackedConv *pc);
-    int pack_conv(const float *W, const float *bias, int M, int K, bool glu, PackedConv *pc);
+    int pack_conv(const float *W, const float *bias, int M, int K, bool glu, PackedConv *pc, int ntaps = 0);
+    int pack_tap(PackedConv *pc, int ntaps);
     int pack_convtr(const float *W, const float *bias, int Cin, int Cout, PackedConv *pc, int stride = 4);
     int pack_vec(const float *v, int n, int npad, bool glu, float **out);
     int pack_linear_ln(const float *W, const float *bias, const float *ln_w, const float *ln_b, int M, int K, PackedConv *pc,

@@ -191,7 +191,19 @@ int Model::pack_half(PackedConv *pc) {
 
 // Conv / Linear weights W[M][K] (K = Cin*K1*K2 flattened) -> Wt[Kpad][Mpad]; `glu` interleaves the
 // two GLU halves: packed row 2c = W[c], 2c+1 = W[c + M/2].
-int Model::pack_conv(const float *W, const float *bias, int M, int K, bool glu, PackedConv *pc) {
+// half modes, k x k stride-1 convs whose input is written as an operand image: third copy of the weights, tap-ordered
+int Model::pack_tap(PackedConv *pc, int ntaps) {
+    static const bool no_tap = getenv("MI_NO_TAP_IMAGE") != nullptr;
+    if (cfg.dtype == MI_DTYPE_F32 || no_tap || ntaps < 2 || pc->K % ntaps || (pc->K / ntaps) % 8) return MI_OK;
+    const int Cin = pc->K / ntaps;
+    MI_TRY(dev_alloc(&pc->wtap, (size_t)16 * conv_tap_pairs_pad(Cin, ntaps) * pc->Mpad));
+    pc->ntaps = ntaps;
+    MI_TRY(launch_pack_tap(pc->wt, pc->Mpad, Cin, ntaps, cfg.dtype, pc->wtap, nullptr));
+    MI_HIP(hipStreamSynchronize(nullptr));
+    return MI_OK;
+}
+
+int Model::pack_conv(const float *W, const float *bias, int M, int K, bool glu, PackedConv *pc, int ntaps) {
     const int tile = conv_pick_tile(M);
     pc->M = M; pc->K = K; pc->Mpad = round_up(M, tile); pc->Kpad = round_up(K, 16); pc->tile = tile;
     std::vector<float> wt((size_t)pc->Kpad * pc->Mpad, 0.f), b(pc->Mpad, 0.f);
@@ -203,6 +215,7 @@ int Model::pack_conv(const float *W, const float *bias, int M, int K, bool glu, 
     MI_TRY(upload(wt, &pc->wt));
     MI_TRY(upload(b, &pc->bias));
     MI_TRY(pack_half(pc));
+    MI_TRY(pack_tap(pc, ntaps));
     return pack_split(pc);
 }
 
@@ -440,7 +453,7 @@ int Model::init(const mi_config &c, const mi_tensor_desc *weights, size_t n) {
         MI_TRY(wt.get(p + ".rewrite.weight", (int64_t)2 * C * C * 9, &rw));
         MI_TRY(wt.get(p + ".rewrite.bias", 2 * C, &rb));
         DecW &dd = dec[j];
-        MI_TRY(pack_conv(rw, rb, 2 * C, C * 9, true, &dd.rewrite));
+        MI_TRY(pack_conv(rw, rb, 2 * C, C * 9, true, &dd.rewrite, 9));
         MI_TRY(make_ktab(Gather{C, 3, 3, 1, 1, 1, 1, (int64_t)Fr * T, T}, dd.rewrite.Kpad, &dd.ktab_rw));
         MI_TRY(load_dconv(wt, p, C, (int64_t)Fr * T, T, true, &dd.dconv));
         MI_TRY(pack_convtr(w, b, C, Cout, &dd.convtr));
@@ -453,7 +466,7 @@ int Model::init(const mi_config &c, const mi_tensor_desc *weights, size_t n) {
         MI_TRY(wt.get(pt + ".rewrite.weight", (int64_t)2 * C * C * 3, &rw));
         MI_TRY(wt.get(pt + ".rewrite.bias", 2 * C, &rb));
         DecW &td = tdec[j];
-        MI_TRY(pack_conv(rw, rb, 2 * C, C * 3, true, &td.rewrite));
+        MI_TRY(pack_conv(rw, rb, 2 * C, C * 3, true, &td.rewrite, 3));
         MI_TRY(make_ktab(Gather{C, 1, 3, 1, 1, 0, 1, (int64_t)L, L}, td.rewrite.Kpad, &td.ktab_rw));
         MI_TRY(load_dconv(wt, pt, C, (int64_t)L, L, false, &td.dconv));
         MI_TRY(pack_convtr(w, b, C, Coutt, &td.convtr));
@@ -951,12 +964,17 @@ int Model::run_core_impl(const float *mix, const float *mag, int B, hipStream_t 
         MI_STAGE("transformer layer done");
     }
     float *din = w_c, *dtin = w_tc;     // decoder inputs (previous output + skip)
+    // half modes: a decoder layer's input feeds nothing but its k x k rewrite conv, so its producer (the channel down-sampler,
+    // then each transposed conv + GELU + skip) writes it ONLY as that conv's 16-bit operand image, into the same buffers, and
+    // the conv gathers its taps by LDS-DMA (gemm_tap.hip)
+    const bool tapimg = cfg.dtype != MI_DTYPE_F32 && dec[0].rewrite.wtap && tdec[0].rewrite.wtap;
     for (int br = 0; br < 2; ++br) {
         const int P = br ? Tt : Tf;
         const Geo g{B, 1, P, 0};
         mi_conv_desc d = base_desc(chan[2 + br], chan_ktab[2 + br], w_tr_x[br][cur[br]], (int64_t)512 * P, g);
         d.plain = 1; d.epi = MI_EPI_LINEAR; d.flags = MI_FLAG_RES; d.res = br ? w_skip_t[3] : w_skip[3];
         d.y = br ? dtin : din; d.y_bstride = (int64_t)384 * P; d.y_cstride = P;
+        if (tapimg) { d.flags |= MI_FLAG_IMG; d.yh = br ? dtin : din; d.yh_n = (int64_t)B * P; }
         MI_TRY(conv(d, br ? stt : st));
     }
     // ---- decoders ----------------------------------------------------------------------------------
@@ -968,6 +986,7 @@ int Model::run_core_impl(const float *mix, const float *mag, int B, hipStream_t 
             const int64_t P = (int64_t)Fr * T;
             mi_conv_desc r = base_desc(dec[j].rewrite, dec[j].ktab_rw, din, C * P, g);
             r.epi = MI_EPI_GLU; r.y = w_a; r.y_bstride = C * P; r.y_cstride = P;
+            if (tapimg) { r.xh = din; r.xh_n = (int64_t)B * P; r.wtap = dec[j].rewrite.wtap; r.ntaps = 9; r.tap_k2 = 3; r.tap_pad1 = 1; r.tap_pad2 = 1; }
             MI_TRY(conv(r, st));
             MI_TRY(run_dconv(dec[j].dconv, C, g, w_a, w_b, w_h, w_stats, w_st1, w_st2, st));
             const int Cout = last ? 4 * S : kCh[2 - j];
@@ -976,6 +995,7 @@ int Model::run_core_impl(const float *mix, const float *mag, int B, hipStream_t 
             t.y_cstride = (int64_t)4 * Fr * T; t.y_bstride = Cout * t.y_cstride;
             if (last) t.y = w_yspec;
             else { t.flags |= MI_FLAG_GELU | MI_FLAG_RES; t.res = w_skip[2 - j]; t.y = din; }
+            if (!last && tapimg) { t.flags |= MI_FLAG_IMG; t.yh = din; t.yh_n = (int64_t)B * t.y_cstride; }
             // din is free to overwrite: the rewrite conv that read it has completed (same stream)
             MI_TRY(conv(t, st));
             MI_STAGE("dec freq layer done");
@@ -985,6 +1005,7 @@ int Model::run_core_impl(const float *mix, const float *mag, int B, hipStream_t 
             const Geo g{B, 1, Lv, 0, L};
             mi_conv_desc r = base_desc(tdec[j].rewrite, tdec[j].ktab_rw, dtin, (int64_t)C * L, g);
             r.epi = MI_EPI_GLU; r.y = w_ta; r.y_bstride = (int64_t)C * L; r.y_cstride = L;
+            if (tapimg) { r.xh = dtin; r.xh_n = (int64_t)B * L; r.wtap = tdec[j].rewrite.wtap; r.ntaps = 3; r.tap_k2 = 3; r.tap_pad1 = 0; r.tap_pad2 = 1; }
             MI_TRY(conv(r, stt));
             MI_TRY(run_dconv(tdec[j].dconv, C, g, w_ta, w_tb, w_th, w_stats_t, w_st1_t, w_st2_t, stt, w_gram2_t, gram2t_bytes));
             const int Cout = last ? 2 * S : kCh[2 - j];
@@ -993,6 +1014,7 @@ int Model::run_core_impl(const float *mix, const float *mag, int B, hipStream_t 
             t.y_cstride = Lpo; t.y_bstride = (int64_t)Cout * Lpo;
             if (last) t.y = w_ytime;
             else { t.flags |= MI_FLAG_GELU | MI_FLAG_RES; t.res = w_skip_t[2 - j]; t.y = dtin; }
+            if (!last && tapimg) { t.flags |= MI_FLAG_IMG; t.yh = dtin; t.yh_n = (int64_t)B * t.y_cstride; }
             MI_TRY(conv(t, stt));
         }
     }

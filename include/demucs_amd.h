@@ -198,6 +198,11 @@ int mi_conv_forward(const struct mi_conv_desc *desc, void *stream);
  *   tile_m must be the tile the layer will run with (64, 96 or 128). */
 int mi_conv_pack_split(const float *wt_dev, int32_t Kpad, int32_t Mpad, int32_t tile_m, void *wx_dev, void *stream);
 
+/* mi_conv_pack_tap: weights of a k x k stride-1 conv for the operand-image route of the half modes (gemm_tap.hip): from the
+ *   packed float32 Wt[Kpad][Mpad] with k = ci * ntaps + tap to the 16-bit image Wtap[pairs][Mpad][8], pair =
+ *   (ci / 8) * ntaps + tap, pairs rounded up to a multiple of 4: 16 * pairs * Mpad bytes.  Cin %% 8 == 0. */
+int mi_conv_pack_tap(const float *wt_dev, int32_t Mpad, int32_t Cin, int32_t ntaps, int32_t dtype, void *wtap_dev, void *stream);
+
 /* Converts fp32 weights Wt[Kpad][Mpad] (the mi_conv_desc.wt layout) into the bf16 / fp16 operand image
  *   Wh[ceil(Kpad/32)*4][Mpad][8] (2 * round_up(Kpad, 32) * Mpad bytes) that mi_conv_desc.wh takes when mi_conv_desc.half
  *   = MI_DTYPE_BF16 / MI_DTYPE_F16 (the load-time half of the reduced-precision compute modes; no reference counterpart). */

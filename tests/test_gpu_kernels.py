@@ -433,6 +433,48 @@ def test_attention_heads_matches_softmax(lib, dtype, Tq, Tk, pitch, spike):
     assert err < ([0, 6e-2, 8e-3][dtype] if spike else [0, 6e-3, 8e-4][dtype])
 
 
+@pytest.mark.parametrize("mode", ["bf16", "f16"])
+@pytest.mark.parametrize("C,Fr,T,Tp", [(16, 6, 40, 40), (48, 5, 77, 77), (24, 1, 301, 304)], ids=["3x3", "3x3-wide", "k3-pitched"])
+def test_tap_image_conv_matches_gather_route(lib, mode, C, Fr, T, Tp):
+    """gemm_tap.hip: the decoders' k x k GLU convs in the half modes read their input as a 16-bit operand image
+    [C / 8][positions][8] and gather the taps by LDS-DMA (k ordered channel-octet, tap, channel % 8).  Same rounded operands as
+    the table-driven float32 -> 16-bit route of gemm_half.hip, so the results agree to float32 summation-order noise; and the
+    float64 convolution of the ROUNDED operands bounds both.  3 x 3 with frame edges, a ragged column tile, and the k = 3
+    time-branch form with a padded row pitch (image columns past the valid length hold NaN: they must never be gathered)."""
+    B = 2
+    time = Fr == 1
+    hdt = torch.bfloat16 if mode == "bf16" else torch.float16
+    dt = {"bf16": 1, "f16": 2}[mode]
+    x = rnd(B, C, Fr, T, seed=201)
+    W, b = (rnd(2 * C, C, 1, 3, seed=202, scale=0.2) if time else rnd(2 * C, C, 3, 3, seed=202, scale=0.1)), rnd(2 * C, seed=203)
+    xr, Wr = x.to(hdt).double(), W.to(hdt).double()
+    z = F.conv2d(xr, Wr, b.double(), padding=(0, 1) if time else 1)
+    want = z[:, :C] * torch.sigmoid(z[:, C:])
+    ntaps = W.shape[2] * W.shape[3]
+    wt, bias, M, Mpad, K, Kpad, tile = pack_w(W.reshape(2 * C, -1), b, glu=True)
+    P = Fr * Tp
+    # the input as its operand image: position n = b * Fr * Tp + fr * Tp + t; pitch columns are NaN
+    xp = torch.full((B, C, Fr, Tp), float("nan"))
+    xp[..., :T] = x
+    img = xp.to(hdt).permute(1, 0, 2, 3).reshape(C // 8, 8, B * P).permute(0, 2, 1).contiguous().cuda()
+    pairs = (C // 8 * ntaps + 3) // 4 * 4
+    wtap = torch.empty(pairs * Mpad * 8, dtype=torch.int16, device="cuda")
+    _lib.check(lib.mi_conv_pack_tap(wt.data_ptr(), Mpad, C, ntaps, dt, wtap.data_ptr(), stream()), "mi_conv_pack_tap")
+    xd = torch.zeros(B, C, Fr, Tp)
+    xd[..., :T] = x
+    xd = xd.float().cuda()
+    common = dict(x6=mode, wt=wt, M=M, Mpad=Mpad, K=K, Kpad=Kpad, ktab=ktab(C, W.shape[2], 3, 1, 1, 0 if time else 1, 1, P, Tp, Kpad), x=xd,
+                  x_bstride=C * P, B=B, D1=Fr, D2=T, O1=Fr, O2=Tp, S1=1, S2=1, row_mode=0 if time else 1, epi=EPI_GLU, bias=bias,
+                  y_bstride=C * P, y_cstride=P, tile_m=tile, o2_valid=T if Tp != T else 0, x_ld=Tp if Tp != T else 0)
+    y_ref, y_tap = torch.zeros(B, C, Fr, Tp, device="cuda"), torch.zeros(B, C, Fr, Tp, device="cuda")
+    conv_call(y=y_ref, **common)
+    conv_call(y=y_tap, xh=img, xh_n=B * P, wtap=wtap, ntaps=ntaps, tap_k2=3, tap_pad1=0 if time else 1, tap_pad2=1, **common)
+    e_ref, e_tap = maxerr(y_ref[..., :T], want), maxerr(y_tap[..., :T], want)
+    print(f"tap conv {mode} C {C} Fr {Fr} T {T}: gather route {e_ref:.2e}, image route {e_tap:.2e} vs float64 on the rounded operands")
+    assert bool(torch.isfinite(y_tap[..., :T]).all())
+    assert e_tap < 2e-5 and e_ref < 2e-5 and maxerr(y_tap[..., :T], y_ref[..., :T]) < 1e-5
+
+
 def test_layernorm_channel_first(lib):
     B, Cn, Tn = 2, 512, 333
     x = rnd(B, Cn, Tn, seed=50) * 3 + 40.0          # large mean: checks the shifted one-pass variance

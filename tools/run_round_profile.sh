@@ -10,14 +10,15 @@ fi
 [ $stage = tests ] && exit 0
 cd /tmp && export TMPDIR=/tmp
 BARE="--no-cpu-baseline --no-host-leg --no-fixed-leg --no-modes-leg"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/prof_f32 -o p --output-format csv -- python3 $R/bench.py --steps 5 --warmup 1 $BARE > $O/prof_f32.log 2>&1
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/prof_bf16 -o p --output-format csv -- python3 $R/bench.py --dtype bf16 --steps 5 --warmup 1 $BARE > $O/prof_bf16.log 2>&1
+# default schedule (waveform branch on a side stream): the timed region alone
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/prof_f32 -o p --output-format csv -- python3 $R/bench.py --steps 5 --warmup 1 --no-iso-pass $BARE > $O/prof_f32.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/prof_bf16 -o p --output-format csv -- python3 $R/bench.py --dtype bf16 --steps 5 --warmup 1 --no-iso-pass $BARE > $O/prof_bf16.log 2>&1
 # the same commands with every launch on one stream (one kernel on the GPU at a time): the per-kernel durations bench.py's roofline quotes
 export MI_ONE_STREAM=1
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/prof_f32_one -o p --output-format csv -- python3 $R/bench.py --steps 5 --warmup 1 $BARE > $O/prof_f32_one.log 2>&1
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/prof_bf16_one -o p --output-format csv -- python3 $R/bench.py --dtype bf16 --steps 5 --warmup 1 $BARE > $O/prof_bf16_one.log 2>&1
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_fetch -o p --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 $BARE > $O/pmc_fetch.log 2>&1
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pmc_write -o p --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 $BARE > $O/pmc_write.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/prof_f32_one -o p --output-format csv -- python3 $R/bench.py --steps 5 --warmup 1 --no-iso-pass $BARE > $O/prof_f32_one.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/prof_bf16_one -o p --output-format csv -- python3 $R/bench.py --dtype bf16 --steps 5 --warmup 1 --no-iso-pass $BARE > $O/prof_bf16_one.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_fetch -o p --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --no-iso-pass $BARE > $O/pmc_fetch.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pmc_write -o p --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --no-iso-pass $BARE > $O/pmc_write.log 2>&1
 unset MI_ONE_STREAM
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/prof_hdemucs_f16 -o p --output-format csv -- python3 $R/tools/micro/hdemucs_profile.py f16 5 > $O/prof_hdemucs.log 2>&1
 cd $R && python3 tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write $O/traffic.json | head -30

@@ -3,7 +3,7 @@ import json
 import sys
 
 d = json.load(open(sys.argv[1]))
-steps = d["steps"]
+steps = d.get("kernels_steps", d["steps"])
 print(f"{d['value']}x RT   {d['ms_per_step']} ms/step   whole path {d.get('whole_path_tflops')} TFLOP/s   roofline {d['roofline']}")
 tot = 0.0
 for k in d["kernels"]:
