@@ -6,8 +6,11 @@ Here the file is read with `torch.load(..., weights_only=True)`: nothing from th
 resolved to an inert stand-in that only carries the qualified name, and `fractions.Fraction` (the `segment` keyword) is the
 only callable allowed to be re-created.  Quantised states (`__quantized`, diffq) are refused: diffq is not available offline.
 
-PARITY UNPINNED: no released checkpoint can be fetched in this environment; the reader is exercised on packages written in
-the same format by the tests (tests/test_states.py).
+No released checkpoint can be fetched in this environment.  PINNED by full-size packages that the reference's own
+`serialize_model` + `torch.save` wrote around reference models built with every keyword of conf/config.yaml
+(tests/golden/pkg_htdemucs.th, pkg_hdemucs.th: tools/make_golden.py `package_fixture`), whose GPU forward through this reader
+equals the reference's, and by the reference constructors' signatures (tests/golden/ref_signatures.json) against which the
+keyword tables of weights.py / hdemucs.py are checked.
 """
 from __future__ import annotations
 
