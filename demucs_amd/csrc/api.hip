@@ -297,6 +297,11 @@ int mi_conv_pack_tap(const float *wt_dev, int32_t Mpad, int32_t Cin, int32_t nta
     return launch_pack_tap(wt_dev, Mpad, Cin, ntaps, dtype, wtap_dev, (hipStream_t)stream);
 }
 
+int mi_f32_to_image(const float *x_dev, int32_t B, int32_t C, int64_t P, int32_t dtype, void *img_dev, void *stream) {
+    MI_REQUIRE(x_dev && img_dev && B > 0 && C > 0 && P > 0, "mi_f32_to_image: bad argument");
+    return launch_f32_to_image(x_dev, B, C, P, dtype, img_dev, (hipStream_t)stream);
+}
+
 int mi_conv_pack_half(const float *wt_dev, int32_t Kpad, int32_t Mpad, int32_t dtype, void *wh_dev, void *stream) {
     MI_REQUIRE(wt_dev && wh_dev && Kpad > 0 && Mpad > 0, "mi_conv_pack_half: bad argument");
     return launch_pack_half(wt_dev, Kpad, Mpad, dtype, wh_dev, (hipStream_t)stream);

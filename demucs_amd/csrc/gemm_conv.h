@@ -101,6 +101,7 @@ typedef struct mi_conv_desc {
        (mi_conv_pack_tap) and the kernel geometry; xh must be set, x / ktab are ignored */
     const void *wtap;
     int32_t ntaps, tap_k2, tap_pad1, tap_pad2; /* K1 * K2 taps, K2 columns per kernel row, padding along d1 / d2                  */
+    int32_t tap_dil1, tap_dil2;                /* tap step along d1 / d2: 0 = 1; -1 for the two taps of a transposed conv (input q - j) */
 } mi_conv_desc;
 
 #ifdef __cplusplus

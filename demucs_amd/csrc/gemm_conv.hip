@@ -395,6 +395,14 @@ int launch_conv(const mi_conv_desc &din, hipStream_t st) {
     MI_REQUIRE(!(d.flags & MI_FLAG_IMG) || d.epi == MI_EPI_CONVTR ||
                (d.half && d.yh && d.epi == MI_EPI_LINEAR && d.M % 8 == 0 && d.yh_n >= (int64_t)d.B * P && ((uintptr_t)d.yh & 15) == 0),
                "conv: MI_FLAG_IMG needs a half-precision LINEAR layer with M %% 8 == 0 and an aligned output image of >= B * P columns");
+    MI_REQUIRE(d.epi != MI_EPI_CONVTR || ((int64_t)d.Mpad * d.y_cstride < (1ll << 30) && (d.tr_stride == 0 || d.tr_stride == 2 || d.tr_stride == 4) &&
+                                          d.M % (d.tr_stride == 2 ? 2 : 4) == 0),
+               "conv: transposed conv needs stride 2 or 4, M a multiple of it and 30-bit output offsets per item");
+    {   // the scatter epilogue is compiled for these flag sets (gemm_tile.h convtr_tile)
+        const int f = d.flags & (MI_FLAG_GELU | MI_FLAG_RES | MI_FLAG_IMG);
+        MI_REQUIRE(d.epi != MI_EPI_CONVTR || f == 0 || (d.tr_stride != 2 && (f == (MI_FLAG_GELU | MI_FLAG_RES) || f == (MI_FLAG_GELU | MI_FLAG_RES | MI_FLAG_IMG))),
+                   "conv: transposed conv epilogue supports no flags, GELU|RES or GELU|RES|IMG (stride 2: no flags), got %d", d.flags);
+    }
     MI_REQUIRE(!(d.flags & MI_FLAG_IMG) || d.epi != MI_EPI_CONVTR ||
                (d.half && d.yh && d.yh_n >= (int64_t)d.B * d.y_cstride && ((uintptr_t)d.yh & 15) == 0),
                "conv: MI_FLAG_IMG on a transposed conv needs a half mode and an output image of >= B * y_cstride positions");

@@ -1,6 +1,8 @@
-// Half modes: k x k convolutions (the decoders' 3 x 3 / k = 3 "rewrite" convs, reference demucs/hdemucs.py:304-314) whose INPUT
-// exists only as a 16-bit operand image  X[Cin / 8][positions][8]  (written by the producing epilogue: the previous layer's
-// transposed conv + GELU + skip, or the bottleneck's channel down-sampler): nothing but this conv reads that tensor.
+// Half modes: stride-1 k x k convolutions whose INPUT exists as a 16-bit operand image  X[Cin / 8][positions][8]:
+//   * the decoders' 3 x 3 / k = 3 "rewrite" convs (reference demucs/hdemucs.py:304-314): their input is written ONLY as that
+//     image by the producing epilogue (the previous layer's transposed conv + GELU + skip, or the channel down-sampler);
+//   * the decoders' transposed convs (hdemucs.py:287,326-334) as s-phase GEMMs with two taps (input q and q - 1): their
+//     input, the DConv branch's float32 output, is converted to an image by one streaming pass (f32_to_image_kernel).
 //
 // K is enumerated TAP-MINOR PER CHANNEL OCTET:  k = ((ci / 8) * ntaps + tap) * 8 + ci % 8.  One LDS row of a K step's B tile
 // (eight consecutive k = eight channels of ONE tap, for 128 consecutive output positions) is then a contiguous run of the
@@ -98,7 +100,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_half_tap_kernel(const mi_con
     const int x_ld = d.x_ld ? d.x_ld : d.D2;                     // row pitch of the input positions (= O2 of this stride-1 conv)
     const int64_t npos = d.xh_n;                                 // positions per channel octet of the image
     // (channel octet, tap) of this wave's octet, advanced by four pairs per K step (scalar arithmetic)
-    const int K2 = d.tap_k2, K1 = ntaps / K2;
+    const int K2 = d.tap_k2, K1 = ntaps / K2, dil1 = d.tap_dil1 ? d.tap_dil1 : 1, dil2 = d.tap_dil2 ? d.tap_dil2 : 1;
     int p_idx = wave, p_oct = wave / ntaps, p_t1 = (wave - p_oct * ntaps) / K2, p_t2 = (wave - p_oct * ntaps) - p_t1 * K2;
 
 #define MI_TAP_TILE(stage)                                                                                            \
@@ -108,7 +110,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_half_tap_kernel(const mi_con
         const uint4 *ga = wimg + (size_t)p_idx * d.Mpad + m0 + lane;                                                  \
         lds_dma16((pin && arow0) ? ga : zero, sa);                                                                    \
         lds_dma16((pin && arow1) ? ga + 64 : zero, sa + 64);                                                          \
-        const int d1 = p_t1 - d.tap_pad1, d2 = p_t2 - d.tap_pad2;                                                     \
+        const int d1 = p_t1 * dil1 - d.tap_pad1, d2 = p_t2 * dil2 - d.tap_pad2;                                       \
         const uint4 *gx = ximg + (size_t)p_oct * npos;                                                                \
         _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                               \
             const int i1 = co1[j] + d1, i2 = co2[j] + d2;                                                             \
@@ -161,25 +163,50 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_half_tap_kernel(const mi_con
     conv_epilogue<TM, TN, EPI, 0>(d, acc, m0, n0, wm, wn, N, P, o2v);
 }
 
-template <int HT, int WM, int WN, int TM, int TN>
+// x[b][C][P] float32 (channel stride P, batch stride C P) -> image [C / 8][B P][8] in one streaming pass (coalesced along positions)
+template <int HT>
+__global__ __launch_bounds__(256) void f32_to_image_kernel(const float *__restrict__ x, int C, int64_t P, int64_t total, uint4 *__restrict__ img) {
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (n >= total) return;
+    const int oct = blockIdx.y;
+    const int64_t b = n / P, p = n - b * P;
+    const float *src = x + ((size_t)b * C + 8 * oct) * P + p;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = src[(size_t)j * P];
+    img[(size_t)oct * total + n] = make_uint4(pack_half2(HT, v[0], v[1]), pack_half2(HT, v[2], v[3]), pack_half2(HT, v[4], v[5]), pack_half2(HT, v[6], v[7]));
+}
+
+int launch_f32_to_image(const float *x, int B, int C, int64_t P, int dtype, void *img, hipStream_t st) {
+    MI_REQUIRE(C % 8 == 0 && (dtype == MI_DTYPE_BF16 || dtype == MI_DTYPE_F16) && ((uintptr_t)img & 15) == 0, "to_image: C %d, dtype %d", C, dtype);
+    const int64_t total = (int64_t)B * P;
+    const dim3 grid((unsigned)((total + 255) / 256), C / 8);
+    if (dtype == MI_DTYPE_BF16) hipLaunchKernelGGL(f32_to_image_kernel<MI_DTYPE_BF16>, grid, dim3(256), 0, st, x, C, P, total, (uint4 *)img);
+    else hipLaunchKernelGGL(f32_to_image_kernel<MI_DTYPE_F16>, grid, dim3(256), 0, st, x, C, P, total, (uint4 *)img);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+
+template <int HT, int WM, int WN, int TM, int TN, int EPI>
 static int launch_tap_cfg(const mi_conv_desc &d, hipStream_t st) {
     constexpr int BM = WM * TM * 32;
     const int64_t N64 = (int64_t)d.B * d.O1 * d.O2;
     MI_REQUIRE(N64 < (1ll << 31) - 256, "conv tap: too many output positions (%lld)", (long long)N64);
     MI_REQUIRE(d.Mpad % BM == 0, "conv tap: Mpad %d not a multiple of the %d-row tile", d.Mpad, BM);
     const int N = (int)N64, MT = d.Mpad / BM, NT = ceil_div(N, BN);
-    hipLaunchKernelGGL((conv_gemm_half_tap_kernel<HT, WM, WN, TM, TN, MI_EPI_GLU>), dim3(grouped_grid(MT, NT, 1)), dim3(256), 0, st, d, N, MT, 1);
+    hipLaunchKernelGGL((conv_gemm_half_tap_kernel<HT, WM, WN, TM, TN, EPI>), dim3(grouped_grid(MT, NT, 1)), dim3(256), 0, st, d, N, MT, 1);
     MI_CHECK_LAUNCH();
     return MI_OK;
 }
 
 // d validated by launch_conv (gemm_conv.hip): half mode, stride-1 conv, GLU epilogue, input image + tap-ordered weights
 int launch_conv_tap(const mi_conv_desc &d, int tile, hipStream_t st) {
-    MI_REQUIRE(d.epi == MI_EPI_GLU && d.S1 == 1 && d.S2 == 1 && d.O1 == d.D1, "conv tap: instantiated for stride-1 GLU convs");
+    MI_REQUIRE((d.epi == MI_EPI_GLU || d.epi == MI_EPI_CONVTR) && d.S1 == 1 && d.S2 == 1, "conv tap: instantiated for stride-1 GLU convs and transposed convs");
     MI_REQUIRE(d.wtap && d.xh && d.ntaps >= 1 && d.tap_k2 >= 1 && d.K % (8 * d.ntaps) == 0 && (((uintptr_t)d.wtap | (uintptr_t)d.xh) & 15) == 0,
                "conv tap: needs the tap-ordered weight image, the input image and K = Cin * ntaps with Cin %% 8 == 0");
     MI_REQUIRE(d.xh_n >= (int64_t)d.B * d.D1 * (d.x_ld ? d.x_ld : d.D2), "conv tap: input image has %lld positions", (long long)d.xh_n);
-#define MI_TAP(W1, W2, T1, T2) (d.half == MI_DTYPE_BF16 ? launch_tap_cfg<MI_DTYPE_BF16, W1, W2, T1, T2>(d, st) : launch_tap_cfg<MI_DTYPE_F16, W1, W2, T1, T2>(d, st))
+#define MI_TAP_E(W1, W2, T1, T2, E) (d.half == MI_DTYPE_BF16 ? launch_tap_cfg<MI_DTYPE_BF16, W1, W2, T1, T2, E>(d, st) : launch_tap_cfg<MI_DTYPE_F16, W1, W2, T1, T2, E>(d, st))
+#define MI_TAP(W1, W2, T1, T2) (d.epi == MI_EPI_GLU ? MI_TAP_E(W1, W2, T1, T2, MI_EPI_GLU) : MI_TAP_E(W1, W2, T1, T2, MI_EPI_CONVTR))
     switch (tile) {
         case 128: return MI_TAP(2, 2, 2, 2);
         case 96: return MI_TAP(1, 4, 3, 1);
@@ -187,6 +214,7 @@ int launch_conv_tap(const mi_conv_desc &d, int tile, hipStream_t st) {
         case 32: return MI_TAP(1, 4, 1, 1);
     }
 #undef MI_TAP
+#undef MI_TAP_E
     return set_error(MI_EINVAL, "conv tap: unsupported tile_m %d", tile);
 }
 

@@ -48,6 +48,77 @@ __device__ __forceinline__ float gather_b(const mi_conv_desc &d, const mi_ktab_e
     return *p;
 }
 
+// Transposed-conv scatter of one 32x32 accumulator tile (stride 2^LG, kernel 2 * stride): row m = (co, phase), column q ->
+// output index o = stride * q + phase - pad of channel co, cropped to [0, out_len).  Branch-free index arithmetic: the column's
+// per-phase offsets `po` and the tile's per-channel offsets are 32-bit and carry "invalid" as a large negative number, so one add
+// gives the offset and its sign the validity; the 16 skip loads are issued together ahead of the arithmetic.  (The first version
+// -- 64-bit index products and short-circuit conditions per element -- cost 64 VALU instructions per value, three times the
+// main loop of a K = 768 tile.)
+struct TrCol {          // column-constant part, computed once per output column
+    int po[4];          // o * ostep per phase, or kTrBad
+    size_t colbase;     // b * y_bstride (+ o2 on the frequency axis)
+    size_t imgbase;     // (b * y_cstride (+ o2)) * 8: position part of the operand-image index, in 16-bit units
+};
+constexpr int kTrBad = -(1 << 30);
+
+template <int LG>
+__device__ __forceinline__ TrCol convtr_column(const mi_conv_desc &d, const ColInfo &c) {
+    const bool trf = d.flags & MI_FLAG_TR_FREQ;
+    const int tpad = d.tr_stride ? d.tr_pad : 2, ostep = trf ? d.O2 : 1;
+    const int oq = ((trf ? c.o1 : c.o2) << LG) - tpad;
+    TrCol t;
+#pragma unroll
+    for (int ph = 0; ph < (1 << LG); ++ph) {
+        const int o = oq + ph;
+        t.po[ph] = (c.valid && (unsigned)o < (unsigned)d.out_len) ? o * ostep : kTrBad;
+    }
+    const int o2 = trf ? c.o2 : 0;
+    t.colbase = c.valid ? (size_t)c.b * d.y_bstride + o2 : 0;
+    t.imgbase = ((size_t)c.b * d.y_cstride + o2) * 8;
+    return t;
+}
+
+// F: the GELU / RES / IMG bits as compile-time constants (with runtime flags hipcc turned the per-element conditions into
+// control flow again); the host admits the three combinations the models use (launch_conv)
+template <int LG, int F>
+__device__ __forceinline__ void convtr_tile(const mi_conv_desc &d, const f32x16 &acc, const float (&biasr)[16], const TrCol &t, int mbase,
+                                            float *sink) {
+    const int cs = (int)d.y_cstride;
+    constexpr bool gelu = F & MI_FLAG_GELU, resf = F & MI_FLAG_RES, imgf = F & MI_FLAG_IMG;
+    // rows of the tile: m = mbase + j, j = (r & 3) + 8 * (r >> 2), mbase % 4 == 0 -> co = co0 + (j >> LG), phase = j & (stride - 1)
+    const int co0 = mbase >> LG, cout = d.M >> LG;
+    int off[16];
+    float resv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int j = (r & 3) + 8 * (r >> 2), co = co0 + (j >> LG);
+        const int rowoff = co < cout ? co * cs : kTrBad;          // one multiply per distinct channel after CSE
+        off[r] = rowoff + t.po[j & ((1 << LG) - 1)];
+    }
+    if (resf) {
+        const float *const rcol = d.res + t.colbase;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) resv[r] = rcol[max(off[r], 0)];
+    }
+    float *const ycol = d.y + t.colbase;
+    unsigned short *const yimg = reinterpret_cast<unsigned short *>(d.yh) + t.imgbase;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float v = acc[r] + biasr[r];
+        if (gelu) v = gelu_exact(v);
+        if (resf) v += resv[r];
+        if (imgf) {
+            // the only reader is the next layer's k x k conv (gemm_tap.hip): 16-bit, [co / 8][position][8]
+            const int j = (r & 3) + 8 * (r >> 2), co = co0 + (j >> LG);
+            const size_t chan = (size_t)(co >> 3) * d.yh_n * 8 + (co & 7);
+            const int pos8 = (off[r] - co * cs) * 8;
+            if (off[r] >= 0) yimg[chan + pos8] = (unsigned short)(pack_half2(d.half, v, 0.f) & 0xffffu);
+        } else {
+            *(off[r] >= 0 ? ycol + off[r] : sink) = v;
+        }
+    }
+}
+
 // PLAIN = 1x1 / linear layer with K % 16 == 0 and (O1*O2) % 4 == 0: no gather table, float4 activation loads.
 // Epilogue shared by the register-staged and the LDS-DMA main loops.
 // acc[a][b][r] is C[m][n] with n = n0 + (wn*TN + b)*32 + li, m = m0 + (wm*TM + a)*32 + (r & 3) + 8 * (r >> 2) + 4 * lh
@@ -71,6 +142,9 @@ __device__ __forceinline__ void conv_epilogue(const mi_conv_desc &d, f32x16 (&ac
             const float2 st = reinterpret_cast<const float2 *>(d.gn_stats)[row];
             gmean = st.x; grstd = st.y;
         }
+        const int tr_lg = d.tr_stride == 2 ? 1 : 2;
+        TrCol trc;
+        if (EPI == MI_EPI_CONVTR) trc = tr_lg == 2 ? convtr_column<2>(d, c) : convtr_column<1>(d, c);
 #pragma unroll
         for (int a = 0; a < TM; ++a) {
             // keep the epilogue of one 32x32 accumulator tile together: without the fence hipcc copies all
@@ -131,6 +205,20 @@ __device__ __forceinline__ void conv_epilogue(const mi_conv_desc &d, f32x16 (&ac
                     *((c.valid && m < d.M) ? ycol + m * cs : sink) = v;
                 }
             } else if (EPI == MI_EPI_GLU || EPI == MI_EPI_GN_GLU) {
+                // as above: one 64-bit column base, 32-bit row offsets, and the tile's eight residual / scale / embedding loads
+                // issued together ahead of the arithmetic (a load -> store round trip per value is latency, not bandwidth)
+                const size_t colbase = c.valid ? (size_t)c.b * d.y_bstride + c.p : 0;
+                float *const ycol = d.y + colbase;
+                const int cs = (int)d.y_cstride;
+                const bool emb = EPI == MI_EPI_GLU && (d.flags & MI_FLAG_EMB);
+                float resv[8], scv[8];
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const int m = mbase + (r & 3) + 8 * (r >> 2), ch = m >> 1;
+                    const bool ok = c.valid && m < d.M;
+                    if (EPI == MI_EPI_GN_GLU) { resv[r >> 1] = d.res[colbase + (ok ? ch * cs : 0)]; scv[r >> 1] = d.scale[ok ? ch : 0]; }
+                    else if (emb) resv[r >> 1] = d.emb[ok ? ch * d.O1 + c.o1 : 0];
+                }
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
                     const int m = mbase + (r & 3) + 8 * (r >> 2);   // even row: value, m+1: gate
@@ -140,12 +228,9 @@ __device__ __forceinline__ void conv_epilogue(const mi_conv_desc &d, f32x16 (&ac
                         vg = (vg - gmean) * grstd * auxr[r + 1] + aux2r[r + 1];
                     }
                     float v = va * sigmoid_f(vg);
-                    const int ch = m >> 1;
-                    const bool ok = c.valid && m < d.M;
-                    const size_t idx = ok ? (size_t)c.b * d.y_bstride + (size_t)ch * d.y_cstride + c.p : 0;
-                    if (EPI == MI_EPI_GN_GLU) v = d.res[idx] + d.scale[ok ? ch : 0] * v;
-                    else if (d.flags & MI_FLAG_EMB) v += d.emb[ok ? ch * d.O1 + c.o1 : 0];
-                    *(ok ? d.y + idx : sink) = v;
+                    if (EPI == MI_EPI_GN_GLU) v = resv[r >> 1] + scv[r >> 1] * v;
+                    else if (emb) v += resv[r >> 1];
+                    *((c.valid && m < d.M) ? ycol + (m >> 1) * cs : sink) = v;
                 }
             } else if (EPI == MI_EPI_BIAS_STATS || EPI == MI_EPI_STATS_ONLY) {
 #pragma unroll
@@ -158,27 +243,10 @@ __device__ __forceinline__ void conv_epilogue(const mi_conv_desc &d, f32x16 (&ac
                     s1 += ok ? v : 0.f; s2 += ok ? v * v : 0.f;
                 }
             } else if (EPI == MI_EPI_CONVTR) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = mbase + (r & 3) + 8 * (r >> 2);
-                    const int lg = d.tr_stride == 2 ? 1 : 2, tpad = d.tr_stride ? d.tr_pad : 2;
-                    const int co = m >> lg, ph = m & ((1 << lg) - 1);
-                    float v = acc[a][b][r] + biasr[r];
-                    if (d.flags & MI_FLAG_GELU) v = gelu_exact(v);
-                    const int o = (((d.flags & MI_FLAG_TR_FREQ) ? c.o1 : c.o2) << lg) + ph - tpad;
-                    const bool ok = c.valid && m < d.M && o >= 0 && o < d.out_len;
-                    const size_t pos = (d.flags & MI_FLAG_TR_FREQ) ? (size_t)o * d.O2 + c.o2 : (size_t)o;
-                    const size_t idx = ok ? (size_t)c.b * d.y_bstride + (size_t)co * d.y_cstride + pos : 0;
-                    if (d.flags & MI_FLAG_RES) v += d.res[idx];
-                    if (d.flags & MI_FLAG_IMG) {
-                        // the only reader is the next layer's k x k conv (gemm_tap.hip): 16-bit, [co / 8][position][8]
-                        unsigned short *dst = reinterpret_cast<unsigned short *>(d.yh) +
-                                              (((size_t)(co >> 3) * d.yh_n + (size_t)c.b * d.y_cstride + pos) * 8 + (co & 7));
-                        if (ok) *dst = (unsigned short)(pack_half2(d.half, v, 0.f) & 0xffffu);
-                        continue;
-                    }
-                    *(ok ? d.y + idx : sink) = v;
-                }
+                if (tr_lg == 1) convtr_tile<1, 0>(d, acc[a][b], biasr, trc, mbase, sink);
+                else if (!(d.flags & MI_FLAG_GELU)) convtr_tile<2, 0>(d, acc[a][b], biasr, trc, mbase, sink);
+                else if (!(d.flags & MI_FLAG_IMG)) convtr_tile<2, MI_FLAG_GELU | MI_FLAG_RES>(d, acc[a][b], biasr, trc, mbase, sink);
+                else convtr_tile<2, MI_FLAG_GELU | MI_FLAG_RES | MI_FLAG_IMG>(d, acc[a][b], biasr, trc, mbase, sink);
             }
         }
         if (EPI == MI_EPI_BIAS_STATS || EPI == MI_EPI_STATS_ONLY) {

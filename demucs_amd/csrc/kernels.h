@@ -92,6 +92,7 @@ int launch_pack_half(const float *wt, int Kpad, int Mpad, int dtype, void *wh, h
 int conv_tap_pairs_pad(int Cin, int ntaps);
 int launch_pack_tap(const float *wt, int Mpad, int Cin, int ntaps, int dtype, void *out, hipStream_t st);
 int launch_conv_tap(const mi_conv_desc &d, int tile, hipStream_t st);
+int launch_f32_to_image(const float *x, int B, int C, int64_t P, int dtype, void *img, hipStream_t st);
 
 // hkernels.hip: the Hybrid Demucs v3 (hdemucs_mmi) path's own kernels
 int launch_row_affine_pitch(const float *x, int B, int C, int L, int out_pitch, const float2 *norm, float *y, hipStream_t st);

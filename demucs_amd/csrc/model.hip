@@ -236,6 +236,7 @@ int Model::pack_convtr(const float *W, const float *bias, int Cin, int Cout, Pac
     MI_TRY(upload(wt, &pc->wt));
     MI_TRY(upload(b, &pc->bias));
     MI_TRY(pack_half(pc));
+    MI_TRY(pack_tap(pc, 2));             // k = 2 ci + j is already (channel, tap) order
     return pack_split(pc);
 }
 
@@ -996,6 +997,12 @@ int Model::run_core_impl(const float *mix, const float *mag, int B, hipStream_t 
             if (last) t.y = w_yspec;
             else { t.flags |= MI_FLAG_GELU | MI_FLAG_RES; t.res = w_skip[2 - j]; t.y = din; }
             if (!last && tapimg) { t.flags |= MI_FLAG_IMG; t.yh = din; t.yh_n = (int64_t)B * t.y_cstride; }
+            if (tapimg && dec[j].convtr.wtap && !last) {    // the outermost layer (K = 96) is bound by its output either way
+                // the DConv branch's float32 output as the transposed conv's operand image (w_b is free again), then the two taps
+                // (input rows q and q - 1) by LDS-DMA
+                MI_TRY(launch_f32_to_image(w_a, B, C, P, cfg.dtype, w_b, st));
+                t.xh = w_b; t.xh_n = (int64_t)B * P; t.wtap = dec[j].convtr.wtap; t.ntaps = 2; t.tap_k2 = 1; t.tap_dil1 = -1;
+            }
             // din is free to overwrite: the rewrite conv that read it has completed (same stream)
             MI_TRY(conv(t, st));
             MI_STAGE("dec freq layer done");
@@ -1015,6 +1022,10 @@ int Model::run_core_impl(const float *mix, const float *mag, int B, hipStream_t 
             if (last) t.y = w_ytime;
             else { t.flags |= MI_FLAG_GELU | MI_FLAG_RES; t.res = w_skip_t[2 - j]; t.y = dtin; }
             if (!last && tapimg) { t.flags |= MI_FLAG_IMG; t.yh = dtin; t.yh_n = (int64_t)B * t.y_cstride; }
+            if (tapimg && tdec[j].convtr.wtap && !last) {
+                MI_TRY(launch_f32_to_image(w_ta, B, C, L, cfg.dtype, w_tb, stt));
+                t.xh = w_tb; t.xh_n = (int64_t)B * L; t.wtap = tdec[j].convtr.wtap; t.ntaps = 2; t.tap_k2 = 2; t.tap_dil2 = -1;
+            }
             MI_TRY(conv(t, stt));
         }
     }

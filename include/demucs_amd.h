@@ -202,6 +202,10 @@ int mi_conv_pack_split(const float *wt_dev, int32_t Kpad, int32_t Mpad, int32_t 
  *   packed float32 Wt[Kpad][Mpad] with k = ci * ntaps + tap to the 16-bit image Wtap[pairs][Mpad][8], pair =
  *   (ci / 8) * ntaps + tap, pairs rounded up to a multiple of 4: 16 * pairs * Mpad bytes.  Cin %% 8 == 0. */
 int mi_conv_pack_tap(const float *wt_dev, int32_t Mpad, int32_t Cin, int32_t ntaps, int32_t dtype, void *wtap_dev, void *stream);
+/* mi_f32_to_image: float32 x (B, C, P) (channel stride P) -> the 16-bit operand image [C / 8][B * P][8] a matrix product reads by
+ *   LDS-DMA (half modes; used where the producer of x cannot write the image itself: the DConv branch's output in front of a
+ *   decoder's transposed conv).  C %% 8 == 0. */
+int mi_f32_to_image(const float *x_dev, int32_t B, int32_t C, int64_t P, int32_t dtype, void *img_dev, void *stream);
 
 /* Converts fp32 weights Wt[Kpad][Mpad] (the mi_conv_desc.wt layout) into the bf16 / fp16 operand image
  *   Wh[ceil(Kpad/32)*4][Mpad][8] (2 * round_up(Kpad, 32) * Mpad bytes) that mi_conv_desc.wh takes when mi_conv_desc.half

@@ -197,6 +197,62 @@ def test_conv_transpose_4phase(lib, freq, x6):
 
 
 @pytest.mark.parametrize("freq", [True, False])
+@pytest.mark.parametrize("mode", ["bf16", "f16"])
+def test_conv_transpose_on_operand_image(lib, freq, mode):
+    """Half modes: the transposed conv as a two-tap gather on the operand image of its input (gemm_tap.hip, taps q and q - 1 by
+    LDS-DMA) against the table-driven route on the same rounded operands and against float64; the float32 -> image pass
+    (`mi_f32_to_image`) is part of the route.  Frequency axis (an extra output row) and ragged time axis with a row pitch."""
+    hdt = torch.bfloat16 if mode == "bf16" else torch.float16
+    dt = {"bf16": 1, "f16": 2}[mode]
+    if freq:
+        B, C, Co, Fr, T = 2, 24, 12, 8, 40
+        x, W, b = rnd(B, C, Fr, T, seed=17), rnd(C, Co, 8, 1, seed=18, scale=0.2), rnd(Co, seed=19)
+        skip = rnd(B, Co, 4 * Fr, T, seed=20)
+        want = F.gelu(F.conv_transpose2d(x.to(hdt).double(), W.to(hdt).double(), b.double(), stride=(4, 1))[..., 2:-2, :]) + skip
+        P, xs = Fr * T, x
+    else:
+        B, C, Co, L, Lp, Lout = 2, 24, 12, 345, 348, 1377
+        x, W, b = rnd(B, C, L, seed=21), rnd(C, Co, 8, seed=22, scale=0.2), rnd(Co, seed=23)
+        skip = rnd(B, Co, Lout, seed=24)
+        want = F.gelu(F.conv_transpose1d(x.to(hdt).double(), W.to(hdt).double(), b.double(), stride=4)[..., 2:2 + Lout]) + skip
+        P = Lp
+        xs = torch.zeros(B, C, Lp)
+        xs[..., :L] = x
+    Wr = W.reshape(C, Co, 8)
+    W2 = torch.zeros(4 * Co, 2 * C, dtype=torch.float64)
+    for r in range(4):
+        for j in range(2):
+            W2[r::4, j::2] = Wr[:, :, r + 4 * j].t()
+    wt, bias, M, Mpad, K, Kpad, tile = pack_w(W2, b.repeat_interleave(4))
+    xd = xs.float().cuda().contiguous()
+    img = torch.empty(C // 8, B * P, 8, dtype=torch.int16, device="cuda")
+    _lib.check(lib.mi_f32_to_image(xd.data_ptr(), B, C, P, dt, img.data_ptr(), stream()), "mi_f32_to_image")
+    torch.cuda.synchronize()
+    assert torch.equal(img, xs.to(hdt).permute(1, 0, 2, 3).reshape(C // 8, 8, B * P).permute(0, 2, 1).contiguous().view(torch.int16).cuda()
+                       if freq else xs.to(hdt).permute(1, 0, 2).reshape(C // 8, 8, B * P).permute(0, 2, 1).contiguous().view(torch.int16).cuda())
+    pairs = (C // 8 * 2 + 3) // 4 * 4
+    wtap = torch.empty(pairs * Mpad * 8, dtype=torch.int16, device="cuda")
+    _lib.check(lib.mi_conv_pack_tap(wt.data_ptr(), Mpad, C, 2, dt, wtap.data_ptr(), stream()), "mi_conv_pack_tap")
+    if freq:
+        common = dict(x6=mode, wt=wt, M=M, Mpad=Mpad, K=K, Kpad=Kpad, ktab=ktab(C, 2, 1, -1, 1, 0, 0, Fr * T, T, Kpad), x=xd, x_bstride=C * P, B=B,
+                      D1=Fr, D2=T, O1=Fr + 1, O2=T, S1=1, S2=1, row_mode=1, epi=EPI_CONVTR, flags=FLAG_TR_FREQ | FLAG_GELU | FLAG_RES,
+                      res=skip.float().cuda(), bias=bias, y_bstride=Co * 4 * Fr * T, y_cstride=4 * Fr * T, out_len=4 * Fr, tile_m=tile)
+        tap = dict(tap_k2=1, tap_dil1=-1)
+        y_ref, y_tap = torch.empty(B, Co, 4 * Fr, T, device="cuda"), torch.empty(B, Co, 4 * Fr, T, device="cuda")
+    else:
+        common = dict(x6=mode, wt=wt, M=M, Mpad=Mpad, K=K, Kpad=Kpad, ktab=ktab(C, 1, 2, 1, -1, 0, 0, Lp, Lp, Kpad), x=xd, x_bstride=C * Lp, B=B,
+                      D1=1, D2=L, O1=1, O2=L + 1, S1=1, S2=1, epi=EPI_CONVTR, flags=FLAG_GELU | FLAG_RES, res=skip.float().cuda(), bias=bias,
+                      y_bstride=Co * Lout, y_cstride=Lout, out_len=Lout, tile_m=tile, x_ld=Lp)
+        tap = dict(tap_k2=2, tap_dil2=-1)
+        y_ref, y_tap = torch.empty(B, Co, Lout, device="cuda"), torch.empty(B, Co, Lout, device="cuda")
+    conv_call(y=y_ref, **common)
+    conv_call(y=y_tap, xh=img, xh_n=B * P, wtap=wtap, ntaps=2, **tap, **common)
+    e_ref, e_tap = maxerr(y_ref, want), maxerr(y_tap, want)
+    print(f"transposed conv {mode} freq={freq}: gather route {e_ref:.2e}, image route {e_tap:.2e}")
+    assert e_tap < 2e-5 and e_ref < 2e-5 and maxerr(y_tap, y_ref) < 1e-5
+
+
+@pytest.mark.parametrize("freq", [True, False])
 def test_dconv_layer_three_passes(lib, freq, x6):
     """One DConv residual layer (demucs.py:138-143,151-154): dilated conv3 + per-row statistics,
     in-place GroupNorm(1)+GELU pass, 1x1 with statistics-only pass, then GroupNorm + GLU + LayerScale +
