@@ -31,7 +31,6 @@ __device__ __forceinline__ f32x16 tmfma(const uint4 a, const uint4 b, const f32x
     else
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(tf16x8, a), __builtin_bit_cast(tf16x8, b), c, 0, 0, 0);
 }
-constexpr int TK = 32;           // K step: four (channel octet, tap) pairs
 }  // namespace
 
 // Wt[Kpad][Mpad] fp32 (k = ci * ntaps + tap) -> Wtap[pairs rounded up to 4][Mpad][8], pair = (ci / 8) * ntaps + tap
