@@ -191,3 +191,16 @@ def test_split_bf16_gemm_mode_keeps_parity():
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "passed" in r.stdout
+
+
+@pytest.mark.skipif(os.environ.get("MI_DCONV_ROW") is not None, reason="already inside the re-run")
+def test_lds_resident_dconv_row_keeps_parity():
+    """MI_DCONV_ROW=lds (dconv_row.hip `dconv_rowlds_kernel`: the C = 48 frequency rows stay in LDS across both residual layers,
+    channels split over four waves; slower than the per-wave kernel, kept selectable): the float64-oracle parity test above must
+    hold unchanged with it.  Fresh process: the switch is read at the first launch."""
+    env = dict(os.environ, MI_DCONV_ROW="lds")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k", "float64_oracle",
+                        "-p", "no:cacheprovider"], env=env, capture_output=True, text=True,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "passed" in r.stdout
