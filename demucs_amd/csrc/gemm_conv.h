@@ -37,6 +37,9 @@ enum mi_epilogue {
  * token-major tensors  yh[row / 512][b][head = (row / 64) % 8][token (pitch yh_n)][row % 64]  -- the operands of
  * attention_heads.hip (Q, K, V are consumed by nothing else: no float32 copy is written) */
 #define MI_FLAG_HEADS 128
+/* LINEAR: also accumulate sum / sum of squares of the stored result per item b into `stats` (float64 atomics, kStatSlots slots:
+ * the GroupNorm that follows a transformer layer needs no pass of its own over the tensor); O2 >= 32 */
+#define MI_FLAG_STATS 256
 /* MI_FLAG_IMG on a CONVTR epilogue (half modes): the scattered result goes to `yh` as the operand image
  * [Cout / 8][yh_n positions][8] of the NEXT layer's k x k conv (position = b * y_cstride + scattered index); y is not written */
 

@@ -387,6 +387,9 @@ int launch_conv(const mi_conv_desc &din, hipStream_t st) {
                "conv: statistics epilogue needs O2 >= 32");
     const int tile = d.tile_m ? d.tile_m : conv_pick_tile(d.M);
     MI_REQUIRE(d.pro == 0, "conv: the fused GroupNorm+GELU prologue was replaced by launch_gn_gelu");
+    MI_REQUIRE(!(d.flags & MI_FLAG_STATS) || (d.epi == MI_EPI_LINEAR && d.stats && d.O2 >= 32 && d.row_mode == 0),
+               "conv: MI_FLAG_STATS needs a LINEAR layer, a statistics buffer and O2 >= 32");
+    if (d.flags & MI_FLAG_STATS) d.wx = nullptr;             // the split-bf16 main loop is not instantiated with the statistics epilogue
     MI_REQUIRE(!(d.flags & MI_FLAG_LN) || (d.pro_stats && d.scale && d.epi == MI_EPI_LINEAR), "conv: MI_FLAG_LN needs pro_stats and scale");
     // plain fast path: a 1x1 / linear layer whose gather is the identity
     const int64_t P = (int64_t)d.O1 * d.O2;
@@ -424,11 +427,12 @@ int launch_conv(const mi_conv_desc &din, hipStream_t st) {
 #define MI_LINEAR(F)                                                \
     case F: return plain ? launch_tile<MI_EPI_LINEAR, F, true>(d, tile, st) : launch_tile<MI_EPI_LINEAR, F, false>(d, tile, st)
     if (d.epi == MI_EPI_LINEAR) {
-        switch (d.flags & (MI_FLAG_GELU | MI_FLAG_SCALE | MI_FLAG_RES | MI_FLAG_LN)) {
+        switch (d.flags & (MI_FLAG_GELU | MI_FLAG_SCALE | MI_FLAG_RES | MI_FLAG_LN | MI_FLAG_STATS)) {
             MI_LINEAR(0);
             MI_LINEAR(MI_FLAG_GELU);
             MI_LINEAR(MI_FLAG_RES);
             MI_LINEAR(MI_FLAG_SCALE | MI_FLAG_RES);
+            MI_LINEAR(MI_FLAG_SCALE | MI_FLAG_RES | MI_FLAG_STATS);
             MI_LINEAR(MI_FLAG_LN);
             MI_LINEAR(MI_FLAG_LN | MI_FLAG_GELU);
         }

@@ -498,7 +498,7 @@ static int launch_conv_half_t(const mi_conv_desc &d, int tile, bool plain, hipSt
 #define MI_LINEAR(F)                                                \
     case F: return plain ? launch_tile_half<HT, MI_EPI_LINEAR, F, true>(d, tile, st) : launch_tile_half<HT, MI_EPI_LINEAR, F, false>(d, tile, st)
     if (d.xh) {         // input given as a 16-bit operand image: lin2 / out_proj, and (256-row tile) the in-projections and lin1
-        const int f = d.flags & (MI_FLAG_GELU | MI_FLAG_SCALE | MI_FLAG_RES | MI_FLAG_LN | MI_FLAG_IMG | MI_FLAG_HEADS);
+        const int f = d.flags & (MI_FLAG_GELU | MI_FLAG_SCALE | MI_FLAG_RES | MI_FLAG_LN | MI_FLAG_IMG | MI_FLAG_HEADS | MI_FLAG_STATS);
         MI_REQUIRE(d.epi == MI_EPI_LINEAR && plain, "conv: an operand-image input needs a plain LINEAR layer");
         // residual epilogues (out_proj, lin2: 340 MB of float32 residual read + output write per launch) keep the 256 x 128 tile
         // at two workgroups per CU, whose epilogues overlap each other's main loops: measured 9.63 ms against 9.79 for the
@@ -508,12 +508,15 @@ static int launch_conv_half_t(const mi_conv_desc &d, int tile, bool plain, hipSt
             if (img256 && d.Mpad % 256 == 0) return launch_half_img256<HT, MI_FLAG_SCALE | MI_FLAG_RES>(d, st);
             return d.Mpad % 256 == 0 ? launch_half_img<HT, 4, MI_FLAG_SCALE | MI_FLAG_RES>(d, st) : launch_half_img<HT, 2, MI_FLAG_SCALE | MI_FLAG_RES>(d, st);
         }
+        if (f == (MI_FLAG_SCALE | MI_FLAG_RES | MI_FLAG_STATS))
+            return d.Mpad % 256 == 0 ? launch_half_img<HT, 4, MI_FLAG_SCALE | MI_FLAG_RES | MI_FLAG_STATS>(d, st)
+                                     : launch_half_img<HT, 2, MI_FLAG_SCALE | MI_FLAG_RES | MI_FLAG_STATS>(d, st);
         if (f == (MI_FLAG_LN | MI_FLAG_HEADS)) return launch_half_img256<HT, MI_FLAG_LN | MI_FLAG_HEADS>(d, st);
         if (f == (MI_FLAG_LN | MI_FLAG_GELU | MI_FLAG_IMG)) return launch_half_img256<HT, MI_FLAG_LN | MI_FLAG_GELU | MI_FLAG_IMG>(d, st);
         return set_error(MI_EINVAL, "conv: an operand-image input is not instantiated for LINEAR flags %d", d.flags);
     }
     if (d.epi == MI_EPI_LINEAR) {
-        switch (d.flags & (MI_FLAG_GELU | MI_FLAG_SCALE | MI_FLAG_RES | MI_FLAG_LN | MI_FLAG_IMG | MI_FLAG_HEADS)) {
+        switch (d.flags & (MI_FLAG_GELU | MI_FLAG_SCALE | MI_FLAG_RES | MI_FLAG_LN | MI_FLAG_IMG | MI_FLAG_HEADS | MI_FLAG_STATS)) {
             MI_LINEAR(MI_FLAG_LN | MI_FLAG_GELU | MI_FLAG_IMG);
             MI_LINEAR(MI_FLAG_LN | MI_FLAG_HEADS);
             MI_LINEAR(0);
@@ -521,6 +524,7 @@ static int launch_conv_half_t(const mi_conv_desc &d, int tile, bool plain, hipSt
             MI_LINEAR(MI_FLAG_RES);
             MI_LINEAR(MI_FLAG_RES | MI_FLAG_IMG);
             MI_LINEAR(MI_FLAG_SCALE | MI_FLAG_RES);
+            MI_LINEAR(MI_FLAG_SCALE | MI_FLAG_RES | MI_FLAG_STATS);
             MI_LINEAR(MI_FLAG_LN);
             MI_LINEAR(MI_FLAG_LN | MI_FLAG_GELU);
         }

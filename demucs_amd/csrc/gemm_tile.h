@@ -180,6 +180,7 @@ __device__ __forceinline__ void conv_epilogue(const mi_conv_desc &d, f32x16 (&ac
                     if (LFLAGS & MI_FLAG_GELU) v = gelu_exact(v);
                     if (LFLAGS & MI_FLAG_SCALE) v *= auxr[r];
                     if (LFLAGS & MI_FLAG_RES) v += resv[r];
+                    if (LFLAGS & MI_FLAG_STATS) { const bool ok = c.valid && m < d.M; s1 += ok ? v : 0.f; s2 += ok ? v * v : 0.f; }
                     if (LFLAGS & MI_FLAG_HEADS) {
                         // four consecutive channels of one head and token: one 8-byte store into that token's 128-byte row
                         vq[r & 3] = v;
@@ -249,7 +250,7 @@ __device__ __forceinline__ void conv_epilogue(const mi_conv_desc &d, f32x16 (&ac
                 else convtr_tile<2, MI_FLAG_GELU | MI_FLAG_RES | MI_FLAG_IMG>(d, acc[a][b], biasr, trc, mbase, sink);
             }
         }
-        if (EPI == MI_EPI_BIAS_STATS || EPI == MI_EPI_STATS_ONLY) {
+        if (EPI == MI_EPI_BIAS_STATS || EPI == MI_EPI_STATS_ONLY || (EPI == MI_EPI_LINEAR && (LFLAGS & MI_FLAG_STATS))) {
             // a wave's 32 columns span at most two statistics rows (O2 >= 32): reduce both groups
             double t1 = (double)s1, t2 = (double)s2;
             t1 += __shfl_xor(t1, 32); t2 += __shfl_xor(t2, 32);          // the two lane halves share a column

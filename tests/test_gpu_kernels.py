@@ -159,6 +159,18 @@ def test_linear_scale_residual_big_k(lib, x6):
               S1=1, S2=1, plain=1, epi=EPI_LINEAR, flags=FLAG_SCALE | FLAG_RES, scale=pack_vec(g, Mpad), res=r.float().cuda(), bias=bias,
               y=y, y_bstride=M * Tn, y_cstride=Tn, tile_m=tile)
     assert maxerr(y, want) < 6e-5
+    # the same layer with MI_FLAG_STATS (256): sum / sum of squares of the stored result per item, float64 atomics into
+    # stats[item][32 slots][2] -- what the GroupNorm after a transformer layer reads (no pass of its own over the tensor)
+    if x6 is not True:                    # the split-bf16 main loop is not instantiated with it (launch_conv falls back)
+        stats = torch.zeros(B, 32, 2, dtype=torch.float64, device="cuda")
+        y2 = torch.empty(B, M, Tn, device="cuda")
+        conv_call(x6=x6, wt=wt, M=M, Mpad=Mpad, K=K, Kpad=Kpad, ktab=kt, x=x.float().cuda(), x_bstride=K * Tn, B=B, D1=1, D2=Tn, O1=1,
+                  O2=Tn, S1=1, S2=1, plain=1, epi=EPI_LINEAR, flags=FLAG_SCALE | FLAG_RES | 256, scale=pack_vec(g, Mpad), res=r.float().cuda(),
+                  bias=bias, y=y2, y_bstride=M * Tn, y_cstride=Tn, tile_m=tile, stats=stats)
+        assert torch.equal(y2, y)
+        got = stats.sum(1).cpu()
+        ref = torch.stack([y.double().sum((1, 2)).cpu(), (y.double() ** 2).sum((1, 2)).cpu()], 1)
+        assert ((got - ref).abs() / ref.abs().clamp_min(1.0)).max().item() < 2e-6, (got, ref)
 
 
 @pytest.mark.parametrize("freq", [True, False])
