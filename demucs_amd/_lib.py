@@ -47,7 +47,7 @@ class MiConvDesc(C.Structure):
         ("o2_valid", C.c_int32), ("ktab_len", C.c_int32), ("sink", C.c_void_p), ("wx", C.c_void_p), ("tr_stride", C.c_int32), ("tr_pad", C.c_int32), ("x_ld", C.c_int32), ("x_ld_pad", C.c_int32), ("wh", C.c_void_p),
         ("xh", C.c_void_p), ("xh_n", C.c_int64), ("yh", C.c_void_p), ("yh_n", C.c_int64),
         ("wtap", C.c_void_p), ("ntaps", C.c_int32), ("tap_k2", C.c_int32), ("tap_pad1", C.c_int32), ("tap_pad2", C.c_int32),
-        ("tap_dil1", C.c_int32), ("tap_dil2", C.c_int32),
+        ("tap_dil1", C.c_int32), ("tap_dil2", C.c_int32), ("yh_pq", C.c_int64),
     ]
 
 

@@ -40,6 +40,12 @@ enum mi_epilogue {
 /* LINEAR: also accumulate sum / sum of squares of the stored result per item b into `stats` (float64 atomics, kStatSlots slots:
  * the GroupNorm that follows a transformer layer needs no pass of its own over the tensor); O2 >= 32 */
 #define MI_FLAG_STATS 256
+/* GLU epilogue, half modes: besides y, the result goes to `yh` as the PHASE-SPLIT operand image of the next encoder conv (k = 8,
+ * s = 4, pad 2 along o1 with MI_FLAG_TR_FREQ, else along o2): index i of that axis lands in plane rho = i % 4 at slot
+ * q = i / 4 + (rho >= 2), image [(channel octet * 4 + rho)][b * yh_pq + q (* O2 + o2)][8].  Output o of the strided conv then reads
+ * slots o and o + 1 of every plane -- taps 2, 6 / 3, 7 / 0, 4 / 1, 5 for rho = 0 .. 3 -- i.e. it is a stride-1 two-tap conv over
+ * 4 C channels that gemm_tap.hip runs by LDS-DMA.  Slots never written (q = 0 of planes 2, 3; past the end) must be zero. */
+#define MI_FLAG_IMG4 512
 /* MI_FLAG_IMG on a CONVTR epilogue (half modes): the scattered result goes to `yh` as the operand image
  * [Cout / 8][yh_n positions][8] of the NEXT layer's k x k conv (position = b * y_cstride + scattered index); y is not written */
 
@@ -105,6 +111,7 @@ typedef struct mi_conv_desc {
     const void *wtap;
     int32_t ntaps, tap_k2, tap_pad1, tap_pad2; /* K1 * K2 taps, K2 columns per kernel row, padding along d1 / d2                  */
     int32_t tap_dil1, tap_dil2;                /* tap step along d1 / d2: 0 = 1; -1 for the two taps of a transposed conv (input q - j) */
+    int64_t yh_pq;                             /* MI_FLAG_IMG4: positions per item and plane of the phase-split output image        */
 } mi_conv_desc;
 
 #ifdef __cplusplus

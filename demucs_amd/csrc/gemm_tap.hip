@@ -62,7 +62,7 @@ int launch_pack_tap(const float *wt, int Mpad, int Cin, int ntaps, int dtype, vo
     return MI_OK;
 }
 
-template <int HT, int WM, int WN, int TM, int TN, int EPI>
+template <int HT, int WM, int WN, int TM, int TN, int EPI, int LFLAGS>
 __global__ __launch_bounds__(256, 2) void conv_gemm_half_tap_kernel(const mi_conv_desc d, const int N, const int MT, const int Gm) {
     constexpr int BM = WM * TM * 32, AP = 128;                  // A rows per octet in LDS (padded: two DMA instructions per octet)
     static_assert(WN * TN * 32 == BN && WM * WN == 4 && BM <= AP, "4 waves, 128 columns, at most 128 rows");
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_half_tap_kernel(const mi_con
         stage = stage == 2 ? 0 : stage + 1;
     }
 #undef MI_TAP_TILE
-    conv_epilogue<TM, TN, EPI, 0>(d, acc, m0, n0, wm, wn, N, P, o2v);
+    conv_epilogue<TM, TN, EPI, LFLAGS>(d, acc, m0, n0, wm, wn, N, P, o2v);
 }
 
 // x[b][C][P] float32 (channel stride P, batch stride C P) -> image [C / 8][B P][8] in one streaming pass (coalesced along positions)
@@ -186,26 +186,29 @@ int launch_f32_to_image(const float *x, int B, int C, int64_t P, int dtype, void
     return MI_OK;
 }
 
-template <int HT, int WM, int WN, int TM, int TN, int EPI>
+template <int HT, int WM, int WN, int TM, int TN, int EPI, int LFLAGS>
 static int launch_tap_cfg(const mi_conv_desc &d, hipStream_t st) {
     constexpr int BM = WM * TM * 32;
     const int64_t N64 = (int64_t)d.B * d.O1 * d.O2;
     MI_REQUIRE(N64 < (1ll << 31) - 256, "conv tap: too many output positions (%lld)", (long long)N64);
     MI_REQUIRE(d.Mpad % BM == 0, "conv tap: Mpad %d not a multiple of the %d-row tile", d.Mpad, BM);
     const int N = (int)N64, MT = d.Mpad / BM, NT = ceil_div(N, BN);
-    hipLaunchKernelGGL((conv_gemm_half_tap_kernel<HT, WM, WN, TM, TN, EPI>), dim3(grouped_grid(MT, NT, 1)), dim3(256), 0, st, d, N, MT, 1);
+    hipLaunchKernelGGL((conv_gemm_half_tap_kernel<HT, WM, WN, TM, TN, EPI, LFLAGS>), dim3(grouped_grid(MT, NT, 1)), dim3(256), 0, st, d, N, MT, 1);
     MI_CHECK_LAUNCH();
     return MI_OK;
 }
 
-// d validated by launch_conv (gemm_conv.hip): half mode, stride-1 conv, GLU epilogue, input image + tap-ordered weights
+// d validated by launch_conv (gemm_conv.hip): half mode, stride-1 conv (the strided encoder convs arrive as stride-1 two-tap convs on
+// a phase-split image, gemm_conv.h MI_FLAG_IMG4), input image + tap-ordered weights; epilogues GLU, transposed-conv scatter, bias + GELU
 int launch_conv_tap(const mi_conv_desc &d, int tile, hipStream_t st) {
-    MI_REQUIRE((d.epi == MI_EPI_GLU || d.epi == MI_EPI_CONVTR) && d.S1 == 1 && d.S2 == 1, "conv tap: instantiated for stride-1 GLU convs and transposed convs");
+    const bool lin_gelu = d.epi == MI_EPI_LINEAR && (d.flags & (MI_FLAG_GELU | MI_FLAG_SCALE | MI_FLAG_RES | MI_FLAG_LN | MI_FLAG_IMG | MI_FLAG_HEADS | MI_FLAG_STATS)) == MI_FLAG_GELU;
+    MI_REQUIRE((d.epi == MI_EPI_GLU || d.epi == MI_EPI_CONVTR || lin_gelu) && d.S1 == 1 && d.S2 == 1,
+               "conv tap: instantiated for stride-1 GLU convs, transposed convs and bias + GELU convs");
     MI_REQUIRE(d.wtap && d.xh && d.ntaps >= 1 && d.tap_k2 >= 1 && d.K % (8 * d.ntaps) == 0 && (((uintptr_t)d.wtap | (uintptr_t)d.xh) & 15) == 0,
                "conv tap: needs the tap-ordered weight image, the input image and K = Cin * ntaps with Cin %% 8 == 0");
     MI_REQUIRE(d.xh_n >= (int64_t)d.B * d.D1 * (d.x_ld ? d.x_ld : d.D2), "conv tap: input image has %lld positions", (long long)d.xh_n);
-#define MI_TAP_E(W1, W2, T1, T2, E) (d.half == MI_DTYPE_BF16 ? launch_tap_cfg<MI_DTYPE_BF16, W1, W2, T1, T2, E>(d, st) : launch_tap_cfg<MI_DTYPE_F16, W1, W2, T1, T2, E>(d, st))
-#define MI_TAP(W1, W2, T1, T2) (d.epi == MI_EPI_GLU ? MI_TAP_E(W1, W2, T1, T2, MI_EPI_GLU) : MI_TAP_E(W1, W2, T1, T2, MI_EPI_CONVTR))
+#define MI_TAP_E(W1, W2, T1, T2, E, F) (d.half == MI_DTYPE_BF16 ? launch_tap_cfg<MI_DTYPE_BF16, W1, W2, T1, T2, E, F>(d, st) : launch_tap_cfg<MI_DTYPE_F16, W1, W2, T1, T2, E, F>(d, st))
+#define MI_TAP(W1, W2, T1, T2) (d.epi == MI_EPI_GLU ? MI_TAP_E(W1, W2, T1, T2, MI_EPI_GLU, 0) : d.epi == MI_EPI_CONVTR ? MI_TAP_E(W1, W2, T1, T2, MI_EPI_CONVTR, 0) : MI_TAP_E(W1, W2, T1, T2, MI_EPI_LINEAR, MI_FLAG_GELU))
     switch (tile) {
         case 128: return MI_TAP(2, 2, 2, 2);
         case 96: return MI_TAP(1, 4, 3, 1);

@@ -212,7 +212,16 @@ __device__ __forceinline__ void conv_epilogue(const mi_conv_desc &d, f32x16 (&ac
                 float *const ycol = d.y + colbase;
                 const int cs = (int)d.y_cstride;
                 const bool emb = EPI == MI_EPI_GLU && (d.flags & MI_FLAG_EMB);
-                float resv[8], scv[8];
+                const bool img4 = EPI == MI_EPI_GLU && (d.flags & MI_FLAG_IMG4);
+                // phase-split operand image of the next strided conv (MI_FLAG_IMG4): plane and slot of this column
+                unsigned *img4p = nullptr;
+                if (img4) {
+                    const bool trf = d.flags & MI_FLAG_TR_FREQ;
+                    const int idx = trf ? c.o1 : c.o2, rho = idx & 3, q = (idx >> 2) + (rho >> 1);
+                    const size_t pos = (size_t)c.b * d.yh_pq + (trf ? (size_t)q * d.O2 + c.o2 : (size_t)q);
+                    img4p = reinterpret_cast<unsigned *>(d.yh) + ((size_t)rho * d.yh_n + pos) * 4;     // 4 dwords per position
+                }
+                float resv[8], scv[8], vprev = 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
                     const int m = mbase + (r & 3) + 8 * (r >> 2), ch = m >> 1;
@@ -232,6 +241,15 @@ __device__ __forceinline__ void conv_epilogue(const mi_conv_desc &d, f32x16 (&ac
                     if (EPI == MI_EPI_GN_GLU) v = resv[r >> 1] + scv[r >> 1] * v;
                     else if (emb) v += resv[r >> 1];
                     *((c.valid && m < d.M) ? ycol + (m >> 1) * cs : sink) = v;
+                    if (img4) {
+                        // channels ch, ch + 1 (ch even) are rows r = 4 j, 4 j + 2 of this lane: one dword of their octet's 16 bytes
+                        if (r & 2) {
+                            const int ch0 = (m >> 1) - 1;
+                            if (c.valid && m < d.M) img4p[(size_t)(ch0 >> 3) * 16 * d.yh_n + ((ch0 & 7) >> 1)] = pack_half2(d.half, vprev, v);
+                        } else {
+                            vprev = v;
+                        }
+                    }
                 }
             } else if (EPI == MI_EPI_BIAS_STATS || EPI == MI_EPI_STATS_ONLY) {
 #pragma unroll

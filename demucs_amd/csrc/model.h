@@ -85,6 +85,7 @@ struct Profiler {
 struct WorkspacePtrs {
     float *w_xt0 = nullptr, *w_zt = nullptr, *w_x0 = nullptr;
     float *w_skip[4] = {}, *w_skip_t[4] = {};
+    void *w_eimg[2][3] = {};     // half modes: phase-split operand images of the encoder outputs 0..2 ([branch][level], gemm_conv.h MI_FLAG_IMG4)
     float *w_a = nullptr, *w_b = nullptr, *w_c = nullptr, *w_h = nullptr;
     float *w_ta = nullptr, *w_tb = nullptr, *w_tc = nullptr, *w_th = nullptr;
     float2 *w_tr_stat[2][2] = {}, *w_tr_stat1[2] = {};   // per-token (mean, rstd) of the layer inputs / of x1
@@ -153,6 +154,7 @@ struct Model : WorkspacePtrs {
     int pack_half(PackedConv *pc);
     int pack_conv(const float *W, const float *bias, int M, int K, bool glu, PackedConv *pc, int ntaps = 0);
     int pack_tap(PackedConv *pc, int ntaps);
+    int pack_enc_tap(const float *W, int Cin, PackedConv *pc);
     int pack_convtr(const float *W, const float *bias, int Cin, int Cout, PackedConv *pc, int stride = 4);
     int pack_vec(const float *v, int n, int npad, bool glu, float **out);
     int pack_linear_ln(const float *W, const float *bias, const float *ln_w, const float *ln_b, int M, int K, PackedConv *pc,

@@ -203,6 +203,31 @@ int Model::pack_tap(PackedConv *pc, int ntaps) {
     return MI_OK;
 }
 
+// half modes, encoder convs (k = 8, s = 4, pad 2) fed by a phase-split image (gemm_conv.h MI_FLAG_IMG4): the same weights as a stride-1
+// two-tap conv over 4 Cin channels -- channel (octet, plane rho, ci % 8), tap j <-> original tap 4 (j - (rho >= 2)) + rho + 2
+int Model::pack_enc_tap(const float *W /* (M, Cin, 8) */, int Cin, PackedConv *pc) {
+    static const bool off = getenv("MI_NO_ENC_IMAGE") != nullptr || getenv("MI_NO_TAP_IMAGE") != nullptr;
+    if (cfg.dtype == MI_DTYPE_F32 || off || Cin % 8) return MI_OK;
+    const int M = pc->M, K = 8 * Cin;
+    std::vector<float> wt((size_t)K * pc->Mpad, 0.f);
+    for (int m = 0; m < M; ++m)
+        for (int ci = 0; ci < Cin; ++ci)
+            for (int rho = 0; rho < 4; ++rho)
+                for (int j = 0; j < 2; ++j) {
+                    const int tau = 4 * (j - (rho >= 2)) + rho + 2, ce = ((ci >> 3) * 4 + rho) * 8 + (ci & 7);
+                    wt[(size_t)(ce * 2 + j) * pc->Mpad + m] = W[((size_t)m * Cin + ci) * 8 + tau];
+                }
+    float *tmp = nullptr;
+    MI_HIP(hipMalloc((void **)&tmp, wt.size() * sizeof(float)));
+    MI_HIP(hipMemcpy(tmp, wt.data(), wt.size() * sizeof(float), hipMemcpyHostToDevice));
+    int r = dev_alloc(&pc->wtap, (size_t)16 * conv_tap_pairs_pad(4 * Cin, 2) * pc->Mpad);
+    if (r == MI_OK) r = launch_pack_tap(tmp, pc->Mpad, 4 * Cin, 2, cfg.dtype, pc->wtap, nullptr);
+    (void)hipStreamSynchronize(nullptr);
+    (void)hipFree(tmp);
+    if (r == MI_OK) pc->ntaps = 2;
+    return r;
+}
+
 int Model::pack_conv(const float *W, const float *bias, int M, int K, bool glu, PackedConv *pc, int ntaps) {
     const int tile = conv_pick_tile(M);
     pc->M = M; pc->K = K; pc->Mpad = round_up(M, tile); pc->Kpad = round_up(K, 16); pc->tile = tile;
@@ -417,6 +442,7 @@ int Model::init(const mi_config &c, const mi_tensor_desc *weights, size_t n) {
         MI_TRY(wt.get(p + ".rewrite.bias", 2 * C, &rb));
         EncW &e = enc[i];
         MI_TRY(pack_conv(w, b, C, Cin * 8, false, &e.conv));
+        if (i) MI_TRY(pack_enc_tap(w, Cin, &e.conv));
         MI_TRY(make_ktab(Gather{Cin, 8, 1, 1, 1, 2, 0, (int64_t)kFr[i] * T, T}, e.conv.Kpad, &e.ktab_conv));
         MI_TRY(pack_conv(rw, rb, 2 * C, C, true, &e.rewrite));
         MI_TRY(make_ktab(Gather{C, 1, 1, 1, 1, 0, 0, (int64_t)kFr[i + 1] * T, T}, e.rewrite.Kpad, &e.ktab_rw));
@@ -430,6 +456,7 @@ int Model::init(const mi_config &c, const mi_tensor_desc *weights, size_t n) {
         MI_TRY(wt.get(pt + ".rewrite.bias", 2 * C, &rb));
         EncW &te = tenc[i];
         MI_TRY(pack_conv(w, b, C, Cint * 8, false, &te.conv));
+        if (i) MI_TRY(pack_enc_tap(w, Cint, &te.conv));
         MI_TRY(make_ktab(Gather{Cint, 1, 8, 1, 1, 0, 2, (int64_t)Lp[i], Lp[i]}, te.conv.Kpad, &te.ktab_conv));
         MI_TRY(pack_conv(rw, rb, 2 * C, C, true, &te.rewrite));
         MI_TRY(make_ktab(Gather{C, 1, 1, 1, 1, 0, 0, (int64_t)Lp[i + 1], Lp[i + 1]}, te.rewrite.Kpad, &te.ktab_rw));
@@ -611,6 +638,15 @@ int Model::fill_workspace(Workspace &w) {
         MI_TRY(A(&w.w_skip[i], nf)); MI_TRY(A(&w.w_skip_t[i], nt));
         big = std::max(big, std::max(nf, nt));
     }
+    if (cfg.dtype != MI_DTYPE_F32)
+        for (int i = 0; i < 3; ++i) {        // phase-split images of the encoder outputs; the never-written slots are the convs' zero padding
+            const size_t pqf = (size_t)(kFr[i + 1] / 4 + 1) * T, pqt = round_up(ceil_div(Lt[i + 1], 4) + 1, 4);
+            float *pf = nullptr, *pt = nullptr;
+            MI_TRY(A(&pf, 2 * kCh[i] * pqf)); MI_TRY(A(&pt, 2 * kCh[i] * pqt));
+            MI_HIP(hipMemset(pf, 0, 2 * kCh[i] * pqf * B * sizeof(float)));
+            MI_HIP(hipMemset(pt, 0, 2 * kCh[i] * pqt * B * sizeof(float)));
+            w.w_eimg[0][i] = pf; w.w_eimg[1][i] = pt;
+        }
     // scratch shared by all U-Net layers (largest layer: 48 x 512 x T)
     MI_TRY(A(&w.w_a, big)); MI_TRY(A(&w.w_b, big)); MI_TRY(A(&w.w_c, big)); MI_TRY(A(&w.w_h, big / 2));
     MI_TRY(A(&w.w_ta, big)); MI_TRY(A(&w.w_tb, big)); MI_TRY(A(&w.w_tc, big)); MI_TRY(A(&w.w_th, big / 2));
@@ -912,6 +948,12 @@ int Model::run_core_impl(const float *mix, const float *mag, int B, hipStream_t 
             mi_conv_desc d = base_desc(enc[i].conv, enc[i].ktab_conv, xf, Cin * Pin, gin);
             d.O1 = kFr[i + 1]; d.S1 = 4; d.epi = MI_EPI_LINEAR; d.flags = MI_FLAG_GELU;
             d.y = w_a; d.y_bstride = C * P; d.y_cstride = P;
+            if (i && enc[i].conv.wtap && w_eimg[0][i - 1]) {
+                // the previous level's output as a phase-split image: a stride-1 two-tap conv over its slots (rows o1, o1 + 1)
+                const int Q = kFr[i] / 4 + 1;
+                d.xh = w_eimg[0][i - 1]; d.xh_n = (int64_t)cfg.max_batch * Q * T; d.wtap = enc[i].conv.wtap; d.ntaps = 2; d.tap_k2 = 1;
+                d.D1 = Q; d.S1 = 1;
+            }
             MI_TRY(conv(d, st));
             MI_STAGE("enc conv done");
             MI_TRY(run_dconv(enc[i].dconv, C, go, w_a, w_b, w_h, w_stats, w_st1, w_st2, st));
@@ -919,6 +961,10 @@ int Model::run_core_impl(const float *mix, const float *mag, int B, hipStream_t 
             mi_conv_desc r = base_desc(enc[i].rewrite, enc[i].ktab_rw, w_a, C * P, go);
             r.plain = 1; r.epi = MI_EPI_GLU; r.y = w_skip[i]; r.y_bstride = C * P; r.y_cstride = P;
             if (i == 0) { r.flags = MI_FLAG_EMB; r.emb = freq_emb; }
+            if (i < 3 && enc[i + 1].conv.wtap && w_eimg[0][i]) {
+                const int64_t pq = (int64_t)(kFr[i + 1] / 4 + 1) * T;
+                r.flags |= MI_FLAG_IMG4 | MI_FLAG_TR_FREQ; r.yh = w_eimg[0][i]; r.yh_pq = pq; r.yh_n = (int64_t)cfg.max_batch * pq;
+            }
             MI_TRY(conv(r, st));
             xf = w_skip[i];
             MI_STAGE("enc rewrite done");
@@ -929,10 +975,19 @@ int Model::run_core_impl(const float *mix, const float *mag, int B, hipStream_t 
             mi_conv_desc d = base_desc(tenc[i].conv, tenc[i].ktab_conv, xt, (int64_t)Cint * Lp[i], gin);
             d.O2 = Lp[i + 1]; d.o2_valid = Lt[i + 1]; d.S2 = 4; d.epi = MI_EPI_LINEAR; d.flags = MI_FLAG_GELU;
             d.y = w_ta; d.y_bstride = C * P; d.y_cstride = P;
+            if (i && tenc[i].conv.wtap && w_eimg[1][i - 1]) {
+                const int Qp = round_up(ceil_div(Lt[i], 4) + 1, 4);
+                d.xh = w_eimg[1][i - 1]; d.xh_n = (int64_t)cfg.max_batch * Qp; d.wtap = tenc[i].conv.wtap; d.ntaps = 2; d.tap_k2 = 2;
+                d.D2 = Qp; d.x_ld = Qp; d.S2 = 1;
+            }
             MI_TRY(conv(d, stt));
             MI_TRY(run_dconv(tenc[i].dconv, C, go, w_ta, w_tb, w_th, w_stats_t, w_st1_t, w_st2_t, stt, w_gram2_t, gram2t_bytes));
             mi_conv_desc r = base_desc(tenc[i].rewrite, tenc[i].ktab_rw, w_ta, C * P, go);
             r.plain = 1; r.epi = MI_EPI_GLU; r.y = w_skip_t[i]; r.y_bstride = C * P; r.y_cstride = P;
+            if (i < 3 && tenc[i + 1].conv.wtap && w_eimg[1][i]) {
+                const int64_t pq = round_up(ceil_div(Lt[i + 1], 4) + 1, 4);
+                r.flags |= MI_FLAG_IMG4; r.yh = w_eimg[1][i]; r.yh_pq = pq; r.yh_n = (int64_t)cfg.max_batch * pq;
+            }
             MI_TRY(conv(r, stt));
             xt = w_skip_t[i];
             MI_STAGE("tenc layer done");

@@ -264,6 +264,100 @@ def test_conv_transpose_on_operand_image(lib, freq, mode):
     assert e_tap < 2e-5 and e_ref < 2e-5 and maxerr(y_tap, y_ref) < 1e-5
 
 
+def _phase_image(v, axis_len, pq, freq, T, hdt):
+    """Host restatement of gemm_conv.h MI_FLAG_IMG4: v (B, C, Len[, T]) float -> int16 image [(C/8) * 4][B * pq][8]; slot
+    q = i // 4 + (i % 4 >= 2) of plane i % 4 (frequency rows: position q * T + t)."""
+    B, C = v.shape[:2]
+    img = torch.zeros(C // 8 * 4, B * pq, 8, dtype=hdt)
+    for i in range(axis_len):
+        rho, q = i % 4, i // 4 + (1 if i % 4 >= 2 else 0)
+        for b in range(B):
+            if freq:
+                blk = v[b, :, i, :].to(hdt).reshape(C // 8, 8, T).permute(0, 2, 1)                  # (oct, T, 8)
+                img[rho::4][:, b * pq + q * T:b * pq + (q + 1) * T, :] = blk
+            else:
+                img[rho::4][:, b * pq + q, :] = v[b, :, i].to(hdt).reshape(C // 8, 8)
+    return img.view(torch.int16)
+
+
+@pytest.mark.parametrize("freq", [True, False])
+@pytest.mark.parametrize("mode", ["bf16", "f16"])
+def test_encoder_conv_on_phase_split_image(lib, freq, mode):
+    """Half modes, encoder levels 1-3: the previous level's 1x1 + GLU epilogue also writes its result as a PHASE-SPLIT 16-bit image
+    (MI_FLAG_IMG4), on which the strided conv (k = 8, s = 4, pad 2; hdemucs.py:110,132-136) is a stride-1 two-tap conv over 4 C
+    channels run by LDS-DMA (gemm_tap.hip).  Checks (a) the epilogue's image against the host restatement of the layout, built from
+    the float32 output of the same launch (never-written slots stay zero), (b) the conv on that image against float64 on the
+    rounded operands, bias + GELU included; frequency rows and a ragged time axis (L = 1373 -> 344)."""
+    hdt = torch.bfloat16 if mode == "bf16" else torch.float16
+    dt = {"bf16": 1, "f16": 2}[mode]
+    _HALF_MODE[0] = mode
+    try:
+        B, C, Co = 2, 24, 40
+        if freq:
+            Fr, T = 32, 40
+            Len, P, Q = Fr, Fr * T, Fr // 4 + 1
+            pq = Q * T
+            x = rnd(B, 2 * C, Fr, T, seed=31)
+        else:
+            L, Lp = 1373, 1376
+            Len, P, Q = L, Lp, (L + 3) // 4 + 1
+            pq = (Q + 3) // 4 * 4
+            x = rnd(B, 2 * C, Lp, seed=31)
+            x[..., L:] = 0
+        Wr, br = rnd(2 * C, 2 * C, seed=32, scale=0.15), rnd(2 * C, seed=33)
+        # (a) producer: 1x1 conv 2C -> 2C + GLU -> C channels, float32 y and the phase image
+        wt, bias, M, Mpad, K, Kpad, tile = pack_w(Wr, br, glu=True)
+        kt = ktab(2 * C, 1, 1, 1, 1, 0, 0, P, P if not freq else T, Kpad)
+        y = torch.zeros(B, C, *((Fr, T) if freq else (Lp,)), device="cuda")
+        img = torch.zeros(C // 8 * 4, B * pq, 8, dtype=torch.int16, device="cuda")
+        geo = dict(D1=Fr, D2=T, O1=Fr, O2=T, row_mode=1) if freq else dict(D1=1, D2=L, O1=1, O2=Lp, o2_valid=L, x_ld=Lp)
+        conv_call(x6=mode, wt=wt, M=M, Mpad=Mpad, K=K, Kpad=Kpad, ktab=kt, x=x.float().cuda(), x_bstride=2 * C * P, B=B, S1=1, S2=1, plain=1,
+                  epi=EPI_GLU, flags=512 | (FLAG_TR_FREQ if freq else 0), bias=bias, y=y, y_bstride=C * P, y_cstride=P, tile_m=tile,
+                  yh=img, yh_n=B * pq, yh_pq=pq, **geo)
+        xd = x.double()
+        z = torch.einsum("mk,bk...->bm...", Wr.double(), xd) + br.double().reshape(1, -1, *([1] * (x.dim() - 2)))
+        want_y = F.glu(z, dim=1)
+        yv = y.cpu() if freq else y.cpu()[..., :L]
+        assert maxerr(yv.cuda(), want_y if freq else want_y[..., :L]) < 2e-5
+        want_img = _phase_image(yv, Len, pq, freq, T if freq else 0, hdt)
+        assert torch.equal(img.cpu(), want_img), "phase-split image differs from the layout restatement"
+        # (b) consumer: strided conv C -> Co on the image
+        W, b = rnd(Co, C, 8, seed=34, scale=0.2), rnd(Co, seed=35)
+        yr = yv.to(hdt).double()                                   # the rounded operand the image holds
+        if freq:
+            want = F.gelu(F.conv2d(yr, W.to(hdt).double()[..., None], b.double(), stride=(4, 1), padding=(2, 0)))
+            Lo = Fr // 4
+        else:
+            want = F.gelu(F.conv1d(F.pad(yr, (0, (-L) % 4)), W.to(hdt).double(), b.double(), stride=4, padding=2))
+            Lo = want.shape[-1]
+        wt2d = torch.zeros(Co, 8 * C, dtype=torch.float64)         # k' = ((oct * 4 + rho) * 8 + c8) * 2 + j  <-  tap 4 (j - (rho >= 2)) + rho + 2
+        for ci in range(C):
+            for rho in range(4):
+                for j in range(2):
+                    tau = 4 * (j - (1 if rho >= 2 else 0)) + rho + 2
+                    wt2d[:, (((ci // 8) * 4 + rho) * 8 + ci % 8) * 2 + j] = W[:, ci, tau]
+        wt2, bias2, M2, Mpad2, K2, Kpad2, tile2 = pack_w(wt2d, b)
+        pairs = (4 * C // 8 * 2 + 3) // 4 * 4
+        wtap = torch.empty(pairs * Mpad2 * 8, dtype=torch.int16, device="cuda")
+        _lib.check(lib.mi_conv_pack_tap(wt2.data_ptr(), Mpad2, 4 * C, 2, dt, wtap.data_ptr(), stream()), "mi_conv_pack_tap")
+        kt2 = ktab(C, 8, 1, 1, 1, 2, 0, 8, 8, Kpad2)               # unused by the image route (the descriptor still carries a table)
+        if freq:
+            y2 = torch.empty(B, Co, Lo, T, device="cuda")
+            geo2 = dict(D1=Q, D2=T, O1=Lo, O2=T, row_mode=1, tap_k2=1, y_bstride=Co * Lo * T, y_cstride=Lo * T)
+        else:
+            Lop = (Lo + 3) // 4 * 4
+            y2 = torch.zeros(B, Co, Lop, device="cuda")
+            geo2 = dict(D1=1, D2=pq, x_ld=pq, O1=1, O2=Lop, o2_valid=Lo, tap_k2=2, y_bstride=Co * Lop, y_cstride=Lop)
+        conv_call(x6=mode, wt=wt2, M=M2, Mpad=Mpad2, K=K2, Kpad=Kpad2, ktab=kt2, x=y, x_bstride=C * P, B=B, S1=1, S2=1, epi=EPI_LINEAR,
+                  flags=FLAG_GELU, bias=bias2, y=y2, tile_m=tile2, xh=img, xh_n=B * pq, wtap=wtap, ntaps=2, **geo2)
+        got = y2 if freq else y2[..., :Lo]
+        err = maxerr(got, want)
+        print(f"encoder conv on the phase-split image, {mode}, freq={freq}: {err:.2e} vs float64 on the rounded operands")
+        assert err < 3e-5
+    finally:
+        _HALF_MODE[0] = None
+
+
 @pytest.mark.parametrize("freq", [True, False])
 def test_dconv_layer_three_passes(lib, freq, x6):
     """One DConv residual layer (demucs.py:138-143,151-154): dilated conv3 + per-row statistics,
