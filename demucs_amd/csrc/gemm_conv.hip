@@ -387,9 +387,9 @@ int launch_conv(const mi_conv_desc &din, hipStream_t st) {
                "conv: statistics epilogue needs O2 >= 32");
     const int tile = d.tile_m ? d.tile_m : conv_pick_tile(d.M);
     MI_REQUIRE(d.pro == 0, "conv: the fused GroupNorm+GELU prologue was replaced by launch_gn_gelu");
-    MI_REQUIRE(!(d.flags & MI_FLAG_IMG4) || (d.epi == MI_EPI_GLU && d.half && d.yh && d.yh_pq > 0 && d.yh_n >= (int64_t)d.B * d.yh_pq && d.M % 16 == 0 &&
+    MI_REQUIRE(!(d.flags & MI_FLAG_IMG4) || (d.epi == MI_EPI_GLU && d.half && d.yh && d.yh_pq > 0 && d.yh_n >= (int64_t)d.B * d.yh_pq && d.M % 32 == 0 &&
                                              ((uintptr_t)d.yh & 15) == 0),
-               "conv: MI_FLAG_IMG4 needs a half-mode GLU layer with M %% 16 == 0 and an aligned phase image of >= B * yh_pq positions per plane");
+               "conv: MI_FLAG_IMG4 needs a half-mode GLU layer with M %% 32 == 0 and an aligned phase image of >= B * yh_pq positions per plane");
     MI_REQUIRE(!(d.flags & MI_FLAG_STATS) || (d.epi == MI_EPI_LINEAR && d.stats && d.O2 >= 32 && d.row_mode == 0),
                "conv: MI_FLAG_STATS needs a LINEAR layer, a statistics buffer and O2 >= 32");
     if (d.flags & MI_FLAG_STATS) d.wx = nullptr;             // the split-bf16 main loop is not instantiated with the statistics epilogue

@@ -222,6 +222,7 @@ __device__ __forceinline__ void conv_epilogue(const mi_conv_desc &d, f32x16 (&ac
                     img4p = reinterpret_cast<unsigned *>(d.yh) + ((size_t)rho * d.yh_n + pos) * 4;     // 4 dwords per position
                 }
                 float resv[8], scv[8], vprev = 0.f;
+                unsigned pk4[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
                     const int m = mbase + (r & 3) + 8 * (r >> 2), ch = m >> 1;
@@ -241,15 +242,20 @@ __device__ __forceinline__ void conv_epilogue(const mi_conv_desc &d, f32x16 (&ac
                     if (EPI == MI_EPI_GN_GLU) v = resv[r >> 1] + scv[r >> 1] * v;
                     else if (emb) v += resv[r >> 1];
                     *((c.valid && m < d.M) ? ycol + (m >> 1) * cs : sink) = v;
-                    if (img4) {
-                        // channels ch, ch + 1 (ch even) are rows r = 4 j, 4 j + 2 of this lane: one dword of their octet's 16 bytes
-                        if (r & 2) {
-                            const int ch0 = (m >> 1) - 1;
-                            if (c.valid && m < d.M) img4p[(size_t)(ch0 >> 3) * 16 * d.yh_n + ((ch0 & 7) >> 1)] = pack_half2(d.half, vprev, v);
-                        } else {
-                            vprev = v;
-                        }
+                    if (img4) {                                // channels ch, ch + 1 (ch even) are rows r = 4 j, 4 j + 2 of this lane
+                        if (r & 2) pk4[r >> 2] = pack_half2(d.half, vprev, v);
+                        else vprev = v;
                     }
+                }
+                if (img4) {
+                    // the tile's 16 channels = two octets; a lane holds pairs (0,1) (4,5) (8,9) (12,13) + 2 lh.  Two v_permlane32_swap
+                    // give the lower half-wave octet 0 and the upper one octet 1 complete: one 16-byte store per lane
+                    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+                    const u2 s02 = __builtin_amdgcn_permlane32_swap(pk4[0], pk4[2], false, false);
+                    const u2 s13 = __builtin_amdgcn_permlane32_swap(pk4[1], pk4[3], false, false);
+                    const int oct = ((mbase - 4 * lh) >> 4) + lh;
+                    if (c.valid && mbase - 4 * lh + 31 < d.M)
+                        *reinterpret_cast<uint4 *>(img4p + (size_t)oct * 16 * d.yh_n) = make_uint4(s02[0], s02[1], s13[0], s13[1]);
                 }
             } else if (EPI == MI_EPI_BIAS_STATS || EPI == MI_EPI_STATS_ONLY) {
 #pragma unroll

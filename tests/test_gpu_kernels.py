@@ -292,7 +292,7 @@ def test_encoder_conv_on_phase_split_image(lib, freq, mode):
     dt = {"bf16": 1, "f16": 2}[mode]
     _HALF_MODE[0] = mode
     try:
-        B, C, Co = 2, 24, 40
+        B, C, Co = 2, 32, 40                   # 2 C output rows of the producer: a multiple of 32 (whole 16-channel tiles)
         if freq:
             Fr, T = 32, 40
             Len, P, Q = Fr, Fr * T, Fr // 4 + 1
