@@ -610,7 +610,8 @@ int Model::alloc_workspace() {
     int dev = 0;
     MI_HIP(hipGetDevice(&dev));
     char key[128];
-    snprintf(key, sizeof(key), "htdemucs dev%d S%d SL%d B%d", dev, S, SL, cfg.max_batch);
+    // half-mode workspaces carry the phase-split encoder images (fill_workspace): float32 and half models do not share one
+    snprintf(key, sizeof(key), "htdemucs dev%d S%d SL%d B%d %s", dev, S, SL, cfg.max_batch, cfg.dtype == MI_DTYPE_F32 ? "f32" : "half");
     std::lock_guard<std::mutex> lock(g_ws_mutex);
     auto it = g_ws.find(key);
     if (it != g_ws.end()) ws = it->second.lock();
