@@ -2,7 +2,9 @@
 //   * the decoders' 3 x 3 / k = 3 "rewrite" convs (reference demucs/hdemucs.py:304-314): their input is written ONLY as that
 //     image by the producing epilogue (the previous layer's transposed conv + GELU + skip, or the channel down-sampler);
 //   * the decoders' transposed convs (hdemucs.py:287,326-334) as s-phase GEMMs with two taps (input q and q - 1): their
-//     input, the DConv branch's float32 output, is converted to an image by one streaming pass (f32_to_image_kernel).
+//     input, the DConv branch's float32 output, is converted to an image by one streaming pass (f32_to_image_kernel);
+//   * the encoders' strided convs of levels 1-3 (k = 8, s = 4, pad 2; hdemucs.py:110,132-136): on the PHASE-SPLIT image the
+//     previous level's 1x1 + GLU epilogue writes (gemm_conv.h MI_FLAG_IMG4) they are stride-1 two-tap convs over 4 Cin channels.
 //
 // K is enumerated TAP-MINOR PER CHANNEL OCTET:  k = ((ci / 8) * ntaps + tap) * 8 + ci % 8.  One LDS row of a K step's B tile
 // (eight consecutive k = eight channels of ONE tap, for 128 consecutive output positions) is then a contiguous run of the
