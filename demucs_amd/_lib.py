@@ -93,6 +93,7 @@ SIGNATURES = {
                                      C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "mi_attention_image": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
                                      C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_void_p]),
+    "mi_lstm_seq": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
     "mi_gn_gelu": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                              C.c_void_p, C.c_void_p]),
     "mi_gram_order": (C.c_int32, [C.c_int32]),

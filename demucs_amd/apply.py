@@ -405,8 +405,8 @@ def device_split_accumulate(model: HTDemucs, base, chunk_offset: int, length: in
     rows = accs[0].shape[0]
     stream = lambda: C.c_void_p(_lib.current_stream_ptr())          # noqa: E731
     B = model.max_batch
-    per = max(1, B // n_tracks)        # offsets per forward: per * n_tracks segments (one track at a time when max_batch < n_tracks)
-    group = n_tracks if B >= n_tracks else 1
+    group = n_tracks if B >= n_tracks else 1      # tracks per forward: all of them, or one at a time when max_batch < n_tracks
+    per = max(1, B // group)           # offsets per forward: per * group segments fill the batch either way
     SL = model.segment_length          # the engine's fixed forward length; a shorter leaf window is
     short = valid_length < SL          # right-padded with zeros like HTDemucs.forward does (htdemucs.py:534-537)
     seg_buf = torch.zeros(B, channels, SL, device=dev, dtype=torch.float32)

@@ -86,31 +86,44 @@ def convert_audio(wav: torch.Tensor, from_samplerate: int, to_samplerate: int, c
 _CLIP_MODES = {"rescale": 1, "clamp": 2, "tanh": 3}
 
 
-def _on_engine_device(t: torch.Tensor, what: str) -> torch.Tensor:
-    if t.device.type != "cuda":
-        raise _lib.EngineError(f"demucs_amd.audio.{what} only runs on device tensors (MI355X); got a {t.device} tensor. "
-                               "There is no CPU implementation in this package.")
-    if t.dtype != torch.float32:
-        raise TypeError(f"{what}: float32 expected, got {t.dtype}")
-    return t.contiguous()
+def _engine_device(*tensors) -> torch.device:
+    """The GPU the kernels run on: the device of the first device tensor, else the current GPU (host tensors -- what
+    `Separator.separate_tensor(host wav)` returns -- are staged through it).  There is no CPU implementation."""
+    for t in tensors:
+        if t is not None and t.device.type == "cuda":
+            return t.device
+    if not torch.cuda.is_available():
+        raise _lib.EngineError("demucs_amd.audio: prevent_clip / two_stems run on the GPU (MI355X) and none is available; "
+                               "there is no CPU implementation in this package.")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _stage(t: torch.Tensor, dev: torch.device, what: str) -> torch.Tensor:
+    """`t` as a contiguous float32 tensor on `dev` (the reference accepts any floating tensor on any device)."""
+    if not t.dtype.is_floating_point:
+        raise TypeError(f"{what}: a floating-point tensor is expected, got {t.dtype}")
+    return t.to(device=dev, dtype=torch.float32).contiguous()
 
 
 def prevent_clip(wav: torch.Tensor, mode="rescale") -> torch.Tensor:
-    """demucs/audio.py:218-234 on the stems' device (`mi_prevent_clip`: the peak of "rescale" is reduced on the device and
-    never visits the host).  The stems of an engine separation with `split=True` and a device mix live in HBM."""
+    """demucs/audio.py:218-234 as a device kernel (`mi_prevent_clip`: the peak of "rescale" is reduced on the device and
+    never visits the host).  Device stems (an engine separation with `split=True` and a device mix) are processed where
+    they live; host stems (what `Separator.separate_tensor(host wav)` returns) are staged H2D / D2H around the kernel;
+    other floating dtypes are computed in float32 and cast back.  NaN samples propagate like torch's `abs().max()`."""
     if mode is None or mode == "none":
         return wav
     assert wav.dtype.is_floating_point, "too late for clipping"
     if mode not in _CLIP_MODES:
         raise ValueError(f"Invalid mode {mode}")
-    x = _on_engine_device(wav, "prevent_clip")
+    dev = _engine_device(wav)
+    x = _stage(wav, dev, "prevent_clip")
     y = torch.empty_like(x)
     if x.numel():
-        with torch.cuda.device(x.device):
-            peak = torch.empty(1, dtype=torch.int32, device=x.device)
+        with torch.cuda.device(dev):
+            peak = torch.empty(1, dtype=torch.int32, device=dev)
             _lib.check(_lib.load().mi_prevent_clip(x.data_ptr(), x.numel(), _CLIP_MODES[mode], peak.data_ptr(), y.data_ptr(),
                                                    C.c_void_p(_lib.current_stream_ptr())), "mi_prevent_clip")
-    return y
+    return y.to(device=wav.device, dtype=wav.dtype)            # like the reference: same device and dtype as the input
 
 
 def two_stems(origin: torch.Tensor, stems: dict, stem: str, other_method: str = "add") -> dict:
@@ -124,19 +137,21 @@ def two_stems(origin: torch.Tensor, stems: dict, stem: str, other_method: str = 
     names = list(stems)
     out = {}
     if other_method in ("add", "minus"):
-        tensors = [_on_engine_device(stems[k], "two_stems") for k in names]
-        if len(tensors) > 8:
+        if len(names) > 8:
             raise ValueError("two_stems: at most 8 stems")
+        dev = _engine_device(*stems.values())
+        tensors = [_stage(stems[k], dev, "two_stems") for k in names]
         n = tensors[0].numel()
-        assert all(t.numel() == n and t.device == tensors[0].device for t in tensors)
+        assert all(t.numel() == n for t in tensors)
         y = torch.empty_like(tensors[0])
         minus = other_method == "minus"
-        org = _on_engine_device(origin, "two_stems") if minus else None
+        org = _stage(origin, dev, "two_stems") if minus else None
         assert org is None or org.numel() == n
         ptrs = (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
         with torch.cuda.device(y.device):
             _lib.check(_lib.load().mi_two_stems(ptrs, len(tensors), names.index(stem), org.data_ptr() if minus else None, int(minus), n,
                                                 y.data_ptr(), C.c_void_p(_lib.current_stream_ptr())), "mi_two_stems")
+        y = y.to(device=stems[stem].device, dtype=stems[stem].dtype)
         if minus:
             out["minus_" + stem] = y
     out[stem] = stems[stem]

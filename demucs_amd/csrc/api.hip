@@ -341,6 +341,35 @@ int mi_gn_gelu(float *x_dev, int32_t B, int32_t C, int32_t C_alloc, int32_t D1, 
 
 int32_t mi_gram_order(int32_t h) { return gram_hp(h); }
 
+int mi_lstm_seq(const float *gx_dev, const float *whh_host, int32_t N, int32_t H, int32_t W, float *out_dev, int32_t mode, void *stream) {
+    MI_REQUIRE(gx_dev && whh_host && out_dev && N > 0 && W > 0 && (H == 192 || H == 384), "mi_lstm_seq: bad argument (H must be 192 or 384)");
+    MI_REQUIRE(mode == 0 || mode == 1, "mi_lstm_seq: mode 0 (one launch per step) or 1 (persistent kernel)");
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<float> packed((size_t)2 * 4 * H * H);
+    pack_lstm_whh(whh_host, H, packed.data());
+    float *wd = nullptr, *state = nullptr;
+    void *scratch = nullptr;
+    unsigned *flag = nullptr;
+    int r = MI_OK;
+    auto fail = [&](hipError_t e, const char *what) { if (e != hipSuccess && r == MI_OK) r = set_error(MI_EHIP, "mi_lstm_seq: %s: %s", what, hipGetErrorString(e)); };
+    fail(hipMalloc((void **)&wd, packed.size() * sizeof(float)), "hipMalloc");
+    fail(hipMalloc((void **)&state, (size_t)6 * N * H * sizeof(float)), "hipMalloc");
+    fail(hipMalloc(&scratch, lstm_persist_scratch_bytes()), "hipMalloc");
+    fail(hipHostMalloc((void **)&flag, 64, hipHostMallocMapped), "hipHostMalloc");
+    if (r == MI_OK) {
+        *flag = 0;
+        fail(hipMemcpyAsync(wd, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice, st), "hipMemcpyAsync");
+        if (r == MI_OK) r = mode ? launch_lstm_persist(gx_dev, wd, N, H, W, out_dev, scratch, flag, st) : launch_lstm_seq(gx_dev, wd, N, H, W, out_dev, state, st);
+        fail(hipStreamSynchronize(st), "hipStreamSynchronize");
+        if (r == MI_OK && *(volatile unsigned *)flag) r = set_error(MI_EHIP, "mi_lstm_seq: the persistent kernel timed out waiting for its hidden-state exchange");
+    }
+    if (wd) (void)hipFree(wd);
+    if (state) (void)hipFree(state);
+    if (scratch) (void)hipFree(scratch);
+    if (flag) (void)hipHostFree(flag);
+    return r;
+}
+
 int mi_gn_gelu_gram(float *x_dev, int32_t B, int32_t h, int32_t C_alloc, int32_t D1, int32_t D2, int32_t pitch, int32_t row_mode,
                     const float *stats_dev, const float *w_dev, const float *b_dev, double *gram_dev, int32_t slots, void *stream) {
     MI_REQUIRE(x_dev && stats_dev && w_dev && b_dev && gram_dev && B > 0 && h > 0 && D1 > 0 && D2 > 0 && slots > 0, "mi_gn_gelu_gram: bad argument");

@@ -32,7 +32,7 @@ enum mi_epilogue {
  * per-column (mean, rstd) of the RAW input in `pro_stats` (float2 per output column):
  *     y = act( rstd[n] * (acc - mean[n] * c1[m]) + c2[m] )                                      */
 #define MI_FLAG_LN 32
-#define MI_FLAG_IMG 64     /* LINEAR, half modes: the result goes to `yh` as a 16-bit operand image instead of `y` */
+#define MI_FLAG_IMG 64     /* LINEAR or GLU (M % 32 == 0), half modes: the result goes to `yh` as a 16-bit operand image instead of `y` */
 /* LINEAR, half modes, attention projections (M = 512 n rows, O1 = 1): the result goes to `yh` ONLY, as 16-bit per-head
  * token-major tensors  yh[row / 512][b][head = (row / 64) % 8][token (pitch yh_n)][row % 64]  -- the operands of
  * attention_heads.hip (Q, K, V are consumed by nothing else: no float32 copy is written) */

@@ -399,8 +399,11 @@ int launch_conv(const mi_conv_desc &din, hipStream_t st) {
     const bool plain = d.plain && d.K == d.Kpad && P % 4 == 0 && d.x_bstride % 4 == 0 && ((uintptr_t)d.x & 15) == 0 &&
                        d.S1 == 1 && d.S2 == 1 && d.D1 == d.O1 && (d.x_ld ? d.x_ld : d.D2) == d.O2;
     MI_REQUIRE(!(d.flags & MI_FLAG_IMG) || d.epi == MI_EPI_CONVTR ||
-               (d.half && d.yh && d.epi == MI_EPI_LINEAR && d.M % 8 == 0 && d.yh_n >= (int64_t)d.B * P && ((uintptr_t)d.yh & 15) == 0),
-               "conv: MI_FLAG_IMG needs a half-precision LINEAR layer with M %% 8 == 0 and an aligned output image of >= B * P columns");
+               (d.half && d.yh && d.epi == MI_EPI_LINEAR && d.M % 8 == 0 && d.yh_n >= (int64_t)d.B * P && ((uintptr_t)d.yh & 15) == 0) ||
+               (d.half && d.yh && d.epi == MI_EPI_GLU && d.M % 32 == 0 && !(d.flags & (MI_FLAG_IMG4 | MI_FLAG_EMB)) && d.yh_n >= (int64_t)d.B * P &&
+                ((uintptr_t)d.yh & 15) == 0),
+               "conv: MI_FLAG_IMG needs a half-precision LINEAR layer with M %% 8 == 0 (or GLU layer with M %% 32 == 0) and an aligned "
+               "output image of >= B * P columns");
     MI_REQUIRE(d.epi != MI_EPI_CONVTR || ((int64_t)d.Mpad * d.y_cstride < (1ll << 30) && (d.tr_stride == 0 || d.tr_stride == 2 || d.tr_stride == 4) &&
                                           d.M % (d.tr_stride == 2 ? 2 : 4) == 0),
                "conv: transposed conv needs stride 2 or 4, M a multiple of it and 30-bit output offsets per item");

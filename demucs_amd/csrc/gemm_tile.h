@@ -212,14 +212,23 @@ __device__ __forceinline__ void conv_epilogue(const mi_conv_desc &d, f32x16 (&ac
                 float *const ycol = d.y + colbase;
                 const int cs = (int)d.y_cstride;
                 const bool emb = EPI == MI_EPI_GLU && (d.flags & MI_FLAG_EMB);
-                const bool img4 = EPI == MI_EPI_GLU && (d.flags & MI_FLAG_IMG4);
+                // MI_FLAG_IMG on a GLU layer (half modes): the result feeds nothing but the next matrix product (hdemucs decoders:
+                // rewrite + GLU -> transposed conv, no DConv between): it goes ONLY to `yh` as the plain operand image
+                // [channel octet][yh_n columns][8]; y is not written
+                const bool imgp = EPI == MI_EPI_GLU && (d.flags & MI_FLAG_IMG);
+                const bool img4 = (EPI == MI_EPI_GLU && (d.flags & MI_FLAG_IMG4)) || imgp;
                 // phase-split operand image of the next strided conv (MI_FLAG_IMG4): plane and slot of this column
                 unsigned *img4p = nullptr;
-                if (img4) {
+                size_t oct_step = 0;                               // dwords between the images of consecutive channel octets
+                if (imgp) {
+                    img4p = reinterpret_cast<unsigned *>(d.yh) + (size_t)(c.valid ? n : 0) * 4;
+                    oct_step = (size_t)4 * d.yh_n;
+                } else if (img4) {
                     const bool trf = d.flags & MI_FLAG_TR_FREQ;
                     const int idx = trf ? c.o1 : c.o2, rho = idx & 3, q = (idx >> 2) + (rho >> 1);
                     const size_t pos = (size_t)c.b * d.yh_pq + (trf ? (size_t)q * d.O2 + c.o2 : (size_t)q);
                     img4p = reinterpret_cast<unsigned *>(d.yh) + ((size_t)rho * d.yh_n + pos) * 4;     // 4 dwords per position
+                    oct_step = (size_t)16 * d.yh_n;
                 }
                 float resv[8], scv[8], vprev = 0.f;
                 unsigned pk4[4] = {0u, 0u, 0u, 0u};
@@ -241,7 +250,7 @@ __device__ __forceinline__ void conv_epilogue(const mi_conv_desc &d, f32x16 (&ac
                     float v = va * sigmoid_f(vg);
                     if (EPI == MI_EPI_GN_GLU) v = resv[r >> 1] + scv[r >> 1] * v;
                     else if (emb) v += resv[r >> 1];
-                    *((c.valid && m < d.M) ? ycol + (m >> 1) * cs : sink) = v;
+                    *((c.valid && m < d.M && !imgp) ? ycol + (m >> 1) * cs : sink) = v;
                     if (img4) {                                // channels ch, ch + 1 (ch even) are rows r = 4 j, 4 j + 2 of this lane
                         if (r & 2) pk4[r >> 2] = pack_half2(d.half, vprev, v);
                         else vprev = v;
@@ -255,7 +264,7 @@ __device__ __forceinline__ void conv_epilogue(const mi_conv_desc &d, f32x16 (&ac
                     const u2 s13 = __builtin_amdgcn_permlane32_swap(pk4[1], pk4[3], false, false);
                     const int oct = ((mbase - 4 * lh) >> 4) + lh;
                     if (c.valid && mbase - 4 * lh + 31 < d.M)
-                        *reinterpret_cast<uint4 *>(img4p + (size_t)oct * 16 * d.yh_n) = make_uint4(s02[0], s02[1], s13[0], s13[1]);
+                        *reinterpret_cast<uint4 *>(img4p + (size_t)oct * oct_step) = make_uint4(s02[0], s02[1], s13[0], s13[1]);
                 }
             } else if (EPI == MI_EPI_BIAS_STATS || EPI == MI_EPI_STATS_ONLY) {
 #pragma unroll

@@ -48,11 +48,14 @@ struct HModel : Model {
     float *x_dh = nullptr, *x_dy1 = nullptr, *x_dy2 = nullptr, *x_dy3 = nullptr, *x_xf = nullptr, *x_gx = nullptr, *x_o0 = nullptr,
           *x_o1 = nullptr, *x_xl = nullptr, *x_qkc = nullptr, *x_att = nullptr, *x_lstm = nullptr;
     float *x_dec[6] = {}, *x_tdec[5] = {}, *x_yt = nullptr, *x_fr = nullptr;
+    float *x_gimg = nullptr, *x_tgimg = nullptr;      // half modes: 16-bit operand images of the decoders' GLU outputs (hmodel.hip)
     double *x_stats = nullptr, *x_stats_t = nullptr;
     float2 *x_st1 = nullptr, *x_st2 = nullptr, *x_st1t = nullptr, *x_st2t = nullptr, *x_nf = nullptr, *x_df = nullptr, *x_nt = nullptr,
            *x_dt = nullptr;
     size_t x_stats_bytes = 0;
     bool x_dirty = false;
+    void *x_lstm_scratch = nullptr;        // lstm.hip: granule buffers + control words of the persistent recurrence kernel
+    unsigned *lstm_timeout = nullptr;      // pinned host word the kernel sets when a wait times out (sticky; checked by every forward)
     std::map<std::string, std::pair<const float *, int64_t>> taps;    // name -> (buffer, floats per item) of the last forward
 
     ~HModel();
@@ -66,6 +69,7 @@ struct HModel : Model {
     int ktab(HGeo &g, const Gather &ga, int Kpad, const mi_ktab_entry **out);
     int load_deep(const WeightTable &wt, const std::string &prefix, int C, HDeepLayerW *l, int d);
     int load_norm(const WeightTable &wt, const std::string &name, int C, float **w, float **b);
+    int run_lstm(const float *gx, const float *whh, int N, int H, int W, float *out, hipStream_t st);
     int run_deep(HGeo &g, HEncW &e, int C, int Tn, int B, float *x, float *tmp, hipStream_t st);
     int group_norm(const float *x, int B, int C, int G, int in_pitch, int in_len, int off, const float *w, const float *b, int glu, int gelu,
                    const float *scale, const float *res, int res_pitch, float *y, int Cout, int out_len, int out_pitch, hipStream_t st,

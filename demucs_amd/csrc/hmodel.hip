@@ -32,6 +32,13 @@ int HModel::halloc(void **p, size_t bytes) {
 }
 HModel::~HModel() {
     for (void *p : hws) (void)hipFree(p);
+    if (lstm_timeout) (void)hipHostFree(lstm_timeout);
+}
+
+// MI_LSTM_STEPS=1: the round-3 recurrence (one launch per time step, hkernels.hip) instead of the persistent kernel of lstm.hip
+static bool lstm_step_chain() {
+    static const bool on = getenv("MI_LSTM_STEPS") != nullptr && atoi(getenv("MI_LSTM_STEPS")) != 0;
+    return on;
 }
 
 int HModel::load_norm(const WeightTable &wt, const std::string &name, int C, float **w, float **b) {
@@ -178,11 +185,11 @@ int HModel::hinit(const mi_config &c, const mi_tensor_desc *weights, size_t n) {
         const int Cout = i ? hCh[i - 1] : 4 * S, Coutt = i ? hCh[i - 1] : 2 * S;
         const std::string p = "decoder." + std::to_string(j), pt = "tdecoder." + std::to_string(j - 1);
         MI_TRY(wt.get(p + ".rewrite.weight", (int64_t)2 * C * C * 9, &rw)); MI_TRY(wt.get(p + ".rewrite.bias", 2 * C, &rb));
-        MI_TRY(pack_conv(rw, rb, 2 * C, C * 9, true, &hdec[j].rewrite));
+        MI_TRY(pack_conv(rw, rb, 2 * C, C * 9, true, &hdec[j].rewrite, 9));     // half modes: + the tap-ordered image (gemm_tap.hip)
         MI_TRY(wt.get(p + ".conv_tr.weight", (int64_t)C * Cout * 8, &w)); MI_TRY(wt.get(p + ".conv_tr.bias", Cout, &b));
         MI_TRY(pack_convtr(w, b, C, Cout, &hdec[j].convtr, 4));
         MI_TRY(wt.get(pt + ".rewrite.weight", (int64_t)2 * C * C * 3, &rw)); MI_TRY(wt.get(pt + ".rewrite.bias", 2 * C, &rb));
-        MI_TRY(pack_conv(rw, rb, 2 * C, C * 3, true, &htdec[j - 1].rewrite));
+        MI_TRY(pack_conv(rw, rb, 2 * C, C * 3, true, &htdec[j - 1].rewrite, 3));
         MI_TRY(wt.get(pt + ".conv_tr.weight", (int64_t)C * Coutt * 8, &w)); MI_TRY(wt.get(pt + ".conv_tr.bias", Coutt, &b));
         MI_TRY(pack_convtr(w, b, C, Coutt, &htdec[j - 1].convtr, 4));
     }
@@ -203,6 +210,7 @@ int HModel::hinit(const mi_config &c, const mi_tensor_desc *weights, size_t n) {
     }
     MI_TRY(A(&x_skip[4], 768 * T)); MI_TRY(A(&x_skip[5], 1536 * T5)); MI_TRY(A(&x_inject, 768 * T));
     MI_TRY(A(&x_a, big)); MI_TRY(A(&x_b, big)); MI_TRY(A(&x_h, big / 2)); MI_TRY(A(&x_ta, big)); MI_TRY(A(&x_tb, big)); MI_TRY(A(&x_th, big / 2));
+    if (c.dtype != MI_DTYPE_F32) { MI_TRY(A(&x_gimg, big / 2)); MI_TRY(A(&x_tgimg, big / 2)); }   // half modes: operand images of the decoders' GLU outputs
     MI_HIP(hipMemset(x_h, 0, (big / 2 + 64) * B * sizeof(float)));        // hidden tensors carry zero padding channels
     MI_HIP(hipMemset(x_th, 0, (big / 2 + 64) * B * sizeof(float)));
     const size_t zsz = std::max<size_t>(3072 * (T5 + 2), std::max<size_t>(3072 * T + 64, 384 * (4 * T + 8)));   // largest: decoder.1's 384 x 8 x T
@@ -213,6 +221,9 @@ int HModel::hinit(const mi_config &c, const mi_tensor_desc *weights, size_t n) {
     MI_TRY(A(&x_xf, 384 * fw)); MI_TRY(A(&x_gx, 3072 * fw)); MI_TRY(A(&x_o0, 768 * fw)); MI_TRY(A(&x_o1, 768 * fw)); MI_TRY(A(&x_xl, 384 * fw));
     MI_TRY(A(&x_qkc, (3 * 384 + 16) * T)); MI_TRY(A(&x_att, 384 * T));
     MI_TRY(A(&x_lstm, 6 * 384 * (fw / 200 + 2)));          // LSTM state: h ping / pong and c for every (direction, sequence)
+    MI_TRY(halloc(&x_lstm_scratch, lstm_persist_scratch_bytes()));
+    MI_HIP(hipHostMalloc((void **)&lstm_timeout, 64, hipHostMallocMapped));
+    *lstm_timeout = 0;
     MI_TRY(A(&x_dec[0], 768 * T)); MI_TRY(A(&x_dec[1], 384 * 8 * T)); MI_TRY(A(&x_dec[2], 192 * 32 * T)); MI_TRY(A(&x_dec[3], 96 * 128 * T));
     MI_TRY(A(&x_dec[4], 48 * 512 * T)); MI_TRY(A(&x_dec[5], (size_t)4 * S * 2048 * T));
     MI_TRY(A(&x_tdec[0], (size_t)384 * lp[4])); MI_TRY(A(&x_tdec[1], (size_t)192 * lp[3])); MI_TRY(A(&x_tdec[2], (size_t)96 * lp[2]));
@@ -280,8 +291,8 @@ int HModel::geometry(int L, HGeo **out) {
         for (int i = 0; i < 5; ++i) g.Lt[i + 1] = (g.Lt[i] + 3) / 4;
         for (int i = 0; i < 6; ++i) g.Lp[i] = round_up(g.Lt[i], 4);
         MI_REQUIRE(g.Lt[5] == g.T, "time branch (%d) and spectrogram (%d frames) disagree", g.Lt[5], g.T);
-        it = geos.emplace(L, g).first;
-        HGeo &G = it->second;
+        HGeo &G = g;                                    // built completely before it enters the cache: a failed table
+                                                        // upload leaves no half-made geometry for later forwards to hit
         for (int i = 0; i < 4; ++i) {                   // DConv of layers 0-3: this geometry's gather tables
             const int C = hCh[i], T = G.Tp;
             for (int br = 0; br < 2; ++br) {
@@ -300,6 +311,7 @@ int HModel::geometry(int L, HGeo **out) {
             }
         }
         MI_HIP(hipDeviceSynchronize());
+        it = geos.emplace(L, std::move(g)).first;
     }
     it->second.last_use = ++use_clock;
     *out = &it->second;
@@ -316,6 +328,11 @@ int HModel::group_norm(const float *x, int B, int C, int G, int in_pitch, int in
     MI_TRY(launch_row_stats(x, B * G, cnt, cnt, x_stats, st));
     MI_TRY(launch_finalize_stats(x_stats, B * G, (double)cnt, 1e-5f, 0, x_st1, nullptr, st));
     return launch_gn_apply(x, B, C, G, in_pitch, off, x_st1, w, b, glu, gelu, scale, res, res_pitch, y, Cout, out_len, out_pitch, st, chan_div);
+}
+
+int HModel::run_lstm(const float *gx, const float *whh, int N, int H, int W, float *out, hipStream_t st) {
+    if (lstm_step_chain()) return launch_lstm_seq(gx, whh, N, H, W, out, x_lstm, st);
+    return launch_lstm_persist(gx, whh, N, H, W, out, x_lstm_scratch, lstm_timeout, st);
 }
 
 // DConv with BLSTM + LocalState (layers 4, 5): rows are batch items, x (B, C, Tn) contiguous; result back in x
@@ -345,15 +362,15 @@ int HModel::run_deep(HGeo &g, HEncW &e, int C, int Tn, int B, float *x, float *t
             gi.plain = 1; gi.epi = MI_EPI_LINEAR; gi.y = x_gx; gi.y_bstride = (int64_t)8 * H * W; gi.y_cstride = W;
             MI_TRY(conv(gi, st));
             if (prof.on) {         // the LSTM recurrence: W dependent launches timed as one span (bench.py's latency roofline of the mode)
-                const int cls = 101;
+                const int cls = 103;         // own row: 101 is Model::run_dconv's dconv_row_kernel
                 Profiler::Pending p{cls, prof.get(), prof.get(), (double)W * 2.0 * 8.0 * H * H * N, (double)W * (8.0 * H * H + 8.0 * H * N) * 4.0, W};
                 MI_HIP(hipEventRecord(p.a, st));
-                MI_TRY(launch_lstm_seq(x_gx, l.whhT[layer], N, H, W, layer ? x_o1 : x_o0, x_lstm, st));
+                MI_TRY(run_lstm(x_gx, l.whhT[layer], N, H, W, layer ? x_o1 : x_o0, st));
                 MI_HIP(hipEventRecord(p.b, st));
                 prof.pending.push_back(p);
-                snprintf(prof.rows[cls].name, sizeof(prof.rows[cls].name), "lstm_step_kernel");
+                snprintf(prof.rows[cls].name, sizeof(prof.rows[cls].name), lstm_step_chain() ? "lstm_step_kernel" : "lstm_persist_kernel");
             } else
-            MI_TRY(launch_lstm_seq(x_gx, l.whhT[layer], N, H, W, layer ? x_o1 : x_o0, x_lstm, st));
+            MI_TRY(run_lstm(x_gx, l.whhT[layer], N, H, W, layer ? x_o1 : x_o0, st));
         }
         MI_TRY(ktab(g, Gather{2 * H, 1, 1, 1, 1, 0, 0, (int64_t)W, W}, l.lin.Kpad, &k));
         mi_conv_desc li = base_desc(l.lin, k, x_o1, (int64_t)2 * H * W, gs);
@@ -387,6 +404,10 @@ int HModel::run_deep(HGeo &g, HEncW &e, int C, int Tn, int B, float *x, float *t
 }
 
 int HModel::hforward(const float *mix, float *out, int B, int L, hipStream_t st) {
+    // sticky: set from the device (lstm.hip) when a hidden-state wait of an EARLIER forward ran out of time -- its output is garbage
+    MI_REQUIRE(!lstm_timeout || *(volatile unsigned *)lstm_timeout == 0,
+               "an earlier forward's persistent LSTM kernel timed out waiting for its hidden-state exchange (GPU oversubscribed by "
+               "other persistent kernels?): results since then are invalid; MI_LSTM_STEPS=1 selects the one-launch-per-step recurrence");
     if (x_dirty) {
         MI_HIP(hipMemsetAsync(x_stats, 0, x_stats_bytes, st));
         MI_HIP(hipMemsetAsync(x_stats_t, 0, x_stats_bytes, st));
@@ -395,7 +416,10 @@ int HModel::hforward(const float *mix, float *out, int B, int L, hipStream_t st)
         x_dirty = false;
     }
     const int r = hforward_impl(mix, out, B, L, st);
-    if (r != MI_OK) x_dirty = true;
+    if (r != MI_OK) {
+        x_dirty = true;
+        if (side_st) (void)hipStreamSynchronize(side_st);      // as Model::run_core: no side-stream kernel outlives a failed forward
+    }
     return r;
 }
 
@@ -556,7 +580,18 @@ int HModel::hforward_impl(const float *mix, float *out, int B, int L, hipStream_
         taps["tdec0+skip"] = {x_tdec[0], (int64_t)384 * Lp[4]};
     }
     // ---- decoder.2-5 / tdecoder.1-4: rewrite 3x3 (k 3) + GLU -> ConvTranspose (+ GELU + next skip) -------------------------
+    // Half modes (round 4, as model.hip's decoders): every tensor between these layers feeds NOTHING BUT the next matrix product
+    // (there is no DConv here: dconv_mode = 1), so it exists only as a 16-bit operand image -- the layer input (written by the
+    // previous transposed conv's GELU + skip epilogue; for the first layer converted from GroupNorm's float32 output), and the
+    // GLU output (written by the rewrite conv's epilogue, MI_FLAG_IMG) -- and both convs gather their taps by LDS-DMA
+    // (gemm_tap.hip) instead of walking a table over float32 tensors.  MI_NO_TAP_IMAGE=1 restores the table-driven route.
+    const bool tapimg = cfg.dtype != MI_DTYPE_F32 && x_gimg && hdec[2].rewrite.wtap && htdec[1].rewrite.wtap && hdec[2].convtr.wtap && htdec[1].convtr.wtap;
+    static const bool last_tap = getenv("MI_H_LAST_TAP") != nullptr;       // A/B: the outermost transposed conv (K = 96) on the image route too
     MI_TRY(fork());
+    if (tapimg) {
+        MI_TRY(launch_f32_to_image(x_dec[1], B, 384, (int64_t)8 * Tp, cfg.dtype, x_b, st));
+        MI_TRY(launch_f32_to_image(x_tdec[0], B, 384, (int64_t)Lp[4], cfg.dtype, x_tb, stt));
+    }
     for (int j = 2; j < 6; ++j) {
         const int i = 5 - j, C = hCh[i], Fr = hFr[i + 1];
         const bool last = j == 5;
@@ -566,6 +601,12 @@ int HModel::hforward_impl(const float *mix, float *out, int B, int L, hipStream_
             MI_TRY(ktab(g, Gather{C, 3, 3, 1, 1, 1, 1, P, Tp}, hdec[j].rewrite.Kpad, &k));
             mi_conv_desc r = base_desc(hdec[j].rewrite, k, x_dec[j - 1], C * P, gg);
             r.epi = MI_EPI_GLU; r.y = x_a; r.y_bstride = C * P; r.y_cstride = P;
+            const bool tr_tap = tapimg && (!last || last_tap);           // this layer's transposed conv reads an image
+            if (tapimg) {
+                r.xh = j == 2 ? (const void *)x_b : (const void *)x_dec[j - 1]; r.xh_n = (int64_t)B * P;
+                r.wtap = hdec[j].rewrite.wtap; r.ntaps = 9; r.tap_k2 = 3; r.tap_pad1 = 1; r.tap_pad2 = 1;
+                if (tr_tap) { r.flags |= MI_FLAG_IMG; r.yh = x_gimg; r.yh_n = (int64_t)B * P; }
+            }
             MI_TRY(conv(r, st));
             const int Cout = last ? 4 * S : hCh[i - 1];
             MI_TRY(ktab(g, Gather{C, 2, 1, -1, 1, 0, 0, P, Tp}, hdec[j].convtr.Kpad, &k));
@@ -573,6 +614,8 @@ int HModel::hforward_impl(const float *mix, float *out, int B, int L, hipStream_
             t.O1 = Fr + 1; t.epi = MI_EPI_CONVTR; t.flags = MI_FLAG_TR_FREQ; t.out_len = 4 * Fr;
             t.y_cstride = (int64_t)4 * Fr * Tp; t.y_bstride = Cout * t.y_cstride; t.y = x_dec[j];
             if (!last) { t.flags |= MI_FLAG_GELU | MI_FLAG_RES; t.res = x_skip[i - 1]; }
+            if (!last && tapimg) { t.flags |= MI_FLAG_IMG; t.yh = x_dec[j]; t.yh_n = (int64_t)B * t.y_cstride; }
+            if (tr_tap) { t.xh = x_gimg; t.xh_n = (int64_t)B * P; t.wtap = hdec[j].convtr.wtap; t.ntaps = 2; t.tap_k2 = 1; t.tap_dil1 = -1; }
             MI_TRY(conv(t, st));
             taps[std::string("dec") + std::to_string(j) + (last ? "" : "+skip")] = {x_dec[j], t.y_bstride};
         }
@@ -582,6 +625,12 @@ int HModel::hforward_impl(const float *mix, float *out, int B, int L, hipStream_
             MI_TRY(ktab(g, Gather{C, 1, 3, 1, 1, 0, 1, (int64_t)Lq, Lq}, htdec[j - 1].rewrite.Kpad, &k));
             mi_conv_desc r = base_desc(htdec[j - 1].rewrite, k, x_tdec[j - 2], (int64_t)C * Lq, gg);
             r.epi = MI_EPI_GLU; r.y = x_ta; r.y_bstride = (int64_t)C * Lq; r.y_cstride = Lq;
+            const bool tr_tap = tapimg && (!last || last_tap);
+            if (tapimg) {
+                r.xh = j == 2 ? (const void *)x_tb : (const void *)x_tdec[j - 2]; r.xh_n = (int64_t)B * Lq;
+                r.wtap = htdec[j - 1].rewrite.wtap; r.ntaps = 3; r.tap_k2 = 3; r.tap_pad1 = 0; r.tap_pad2 = 1;
+                if (tr_tap) { r.flags |= MI_FLAG_IMG; r.yh = x_tgimg; r.yh_n = (int64_t)B * Lq; }
+            }
             MI_TRY(conv(r, stt));
             const int Cout = last ? 2 * S : hCh[i - 1];
             MI_TRY(ktab(g, Gather{C, 1, 2, 1, -1, 0, 0, (int64_t)Lq, Lq}, htdec[j - 1].convtr.Kpad, &k));
@@ -589,6 +638,8 @@ int HModel::hforward_impl(const float *mix, float *out, int B, int L, hipStream_
             t.O2 = Lv + 1; t.o2_valid = 0; t.epi = MI_EPI_CONVTR; t.out_len = Lout;
             t.y_cstride = Lpo; t.y_bstride = (int64_t)Cout * Lpo; t.y = x_tdec[j - 1];
             if (!last) { t.flags |= MI_FLAG_GELU | MI_FLAG_RES; t.res = x_skip_t[i - 1]; }
+            if (!last && tapimg) { t.flags |= MI_FLAG_IMG; t.yh = x_tdec[j - 1]; t.yh_n = (int64_t)B * t.y_cstride; }
+            if (tr_tap) { t.xh = x_tgimg; t.xh_n = (int64_t)B * Lq; t.wtap = htdec[j - 1].convtr.wtap; t.ntaps = 2; t.tap_k2 = 2; t.tap_dil2 = -1; }
             MI_TRY(conv(t, stt));
             taps[std::string("tdec") + std::to_string(j - 1) + (last ? "" : "+skip")] = {x_tdec[j - 1], t.y_bstride};
         }

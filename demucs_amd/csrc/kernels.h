@@ -103,6 +103,11 @@ int launch_unfold_frames(const float *x, int B, int C, int T, int F, int W, int 
 int launch_restitch_frames(const float *fr, int B, int C, int T, int F, int W, int S, const float *skip, float *y, hipStream_t st);
 void pack_lstm_whh(const float *whh /* (2, 4H, H) */, int H, float *packed);     // host side: the step kernel's operand order
 int launch_lstm_seq(const float *gx, const float *whh /* packed */, int N, int H, int W, float *out, float *state /* 6 N H floats */, hipStream_t st);
+// lstm.hip: the same recurrence as ONE persistent launch per batch of sequence tiles (hidden state exchanged between workgroups
+// as tagged 8-byte granules); scratch: lstm_persist_scratch_bytes() device bytes; ctl_host: pinned host word set on a time-out
+size_t lstm_persist_scratch_bytes();
+int launch_lstm_persist(const float *gx, const float *whh /* packed */, int N, int H, int W, float *out, void *scratch, unsigned *ctl_host,
+                        hipStream_t st);
 int launch_local_attn(const float *qkc, int B, int C, int T, int ld /* row pitch of qkc, % 4 == 0 */, float *out, int ld_o, hipStream_t st);
 
 // attention.hip

@@ -658,7 +658,9 @@ int Model::fill_workspace(Workspace &w) {
     for (int br = 0; br < 2; ++br) {
         const size_t P = br ? Tt : Tf;
         MI_TRY(A(&w.w_tr_x[br][0], 512 * P)); MI_TRY(A(&w.w_tr_x[br][1], 512 * P));
-        MI_TRY(A(&w.w_tr_ximg[br][0], 256 * P)); MI_TRY(A(&w.w_tr_ximg[br][1], 256 * P)); MI_TRY(A(&w.w_tr_x1img[br], 256 * P));
+        if (cfg.dtype != MI_DTYPE_F32) {       // half modes only: operand images of the layer inputs and of x1 (never read in f32)
+            MI_TRY(A(&w.w_tr_ximg[br][0], 256 * P)); MI_TRY(A(&w.w_tr_ximg[br][1], 256 * P)); MI_TRY(A(&w.w_tr_x1img[br], 256 * P));
+        }
         for (int q = 0; q < 2; ++q) MI_TRY(dev_alloc((void **)&w.w_tr_stat[br][q], B * P * sizeof(float2)));
         MI_TRY(dev_alloc((void **)&w.w_tr_stat1[br], B * P * sizeof(float2)));
         MI_TRY(A(&w.w_tr_qkv[br], 1536 * Tf)) /* cross layers: Q (512 x Tq) + KV (1024 x Tk) */; MI_TRY(A(&w.w_tr_att[br], 512 * P));
@@ -875,7 +877,13 @@ int Model::run_core(const float *mix, const float *mag, int B, hipStream_t st) {
         ws->dirty = false;
     }
     const int r = run_core_impl(mix, mag, B, st);
-    if (r != MI_OK) ws->dirty = true;
+    if (r != MI_OK) {
+        ws->dirty = true;
+        // a failure between fork() and the final join() leaves the side stream running kernels on the shared workspace that
+        // the caller's stream never waits for: drain it here, so that the next forward's re-zeroing (and any other handle of
+        // this workspace) cannot race with them
+        if (side_st) (void)hipStreamSynchronize(side_st);
+    }
     return r;
 }
 

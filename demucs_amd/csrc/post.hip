@@ -73,12 +73,13 @@ __global__ __launch_bounds__(256) void track_affine_kernel(float *__restrict__ x
     }
 }
 
-// peak = max |x| as the bit pattern of a non-negative float (unsigned order == float order; max is order-independent)
+// peak = max |x| as the bit pattern of a non-negative float (unsigned order == float order; max is order-independent).  The
+// reduction runs on the bit patterns: |NaN| orders above +inf, so a NaN sample reaches `peak` as torch's abs().max() propagates it
 __global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ x, int64_t n, unsigned *__restrict__ peak) {
-    float m = 0.f;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    if ((threadIdx.x & 63) == 0) atomicMax(peak, __float_as_uint(m));
+    unsigned m = 0u;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = max(m, __float_as_uint(fabsf(x[i])));
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(peak, m);
 }
 
 // mode 1 "rescale": x / max(1.01 * peak, 1); 2 "clamp": clamp(x, -0.99, 0.99); 3 "tanh"   (audio.py:225-231)
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(256) void prevent_clip_kernel(const float *__restri
     float r;
     if (mode == 1) {
         const float d = __fmul_rn(__uint_as_float(*peak), 1.01f);
-        r = d > 1.0f ? __fdiv_rn(v, d) : v;
+        r = (d > 1.0f || d != d) ? __fdiv_rn(v, d) : v;       // a NaN peak divides everything (python's max(nan_tensor, 1) keeps the NaN)
     } else if (mode == 2) {
         r = fminf(fmaxf(v, -0.99f), 0.99f);
     } else {

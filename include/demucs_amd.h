@@ -255,6 +255,13 @@ int mi_gn_gelu_gram(float *x_dev, int32_t B, int32_t h, int32_t C_alloc, int32_t
 int mi_gram_finalize(double *gram_dev, int32_t rows, int32_t h, int32_t slots, const double *wt_dev, const double *ct_dev, double sum_b,
                      double sum_bsq, double cols, double count, float eps, float *stats_out_dev, void *stream);
 
+/* The recurrence of one bidirectional nn.LSTM layer as the BLSTM of demucs/demucs.py:20-67 runs it (zero initial state, gate order
+ *   i, f, g, o): gx_dev (N, 2 directions, 4H, W) = W_ih x_t + b_ih + b_hh for every step (a GEMM done before), whh_host = the HOST
+ *   array (2, 4H, H) of weight_hh_l{k} / weight_hh_l{k}_reverse; out_dev (N, 2H, W): forward hidden states in channels [0, H), backward
+ *   ones in [H, 2H).  H = 192 or 384 (hdemucs_mmi's layers 4 / 5).  mode 0: one launch per time step; mode 1: the persistent kernel
+ *   the engine uses (hidden state exchanged between workgroups as tagged 8-byte granules, bounded waits).  Synchronous (test entry). */
+int mi_lstm_seq(const float *gx_dev, const float *whh_host, int32_t N, int32_t H, int32_t W, float *out_dev, int32_t mode, void *stream);
+
 /* LayerNorm over the channel axis of channel-first tokens x (B, C, T), optional additive table
  *   add_dev (C, T) (nn.LayerNorm at demucs/transformer.py:434-436,591-592 + positional
  *   embedding add :655-663). */

@@ -97,6 +97,25 @@ def test_device_scheduler_is_bit_identical_to_per_segment_route(length, max_batc
     assert torch.equal(fast, slow)
 
 
+def test_more_tracks_than_max_batch_still_fills_the_batch():
+    """A batch of 3 mixes through an engine with max_batch = 2: the tracks go one at a time, each forward still carries
+    max_batch segments (4 segments per track -> 2 forwards per track, 6 in all; round 3 ran 12 one-segment forwards), and the
+    result equals the per-track calls bit for bit."""
+    m = engine(2, 2)
+    length = int(2.3 * SL) + 7
+    mix = torch.stack([torch.from_numpy(synth_mix(60 + k, length, "tones" if k & 1 else "noise")) for k in range(3)]).cuda()
+    calls = []
+    inner = m.forward_segments
+    m.forward_segments = lambda seg, out: (calls.append(seg.shape[0]), inner(seg, out))[1]
+    try:
+        fast = P.apply_model(m, mix, shifts=0, overlap=0.25)
+    finally:
+        del m.forward_segments
+    assert calls == [2] * 6, calls
+    for k in range(3):
+        assert torch.equal(fast[k], P.apply_model(m, mix[k:k + 1], shifts=0, overlap=0.25)[0])
+
+
 def test_shorter_segment_override_and_errors():
     """`segment=5`: the leaf window is int(5 * sr) = 220500 samples, centred on the chunk; the model
     right-pads it to its training length (apply.py:304-305, htdemucs.py:534-537)."""

@@ -233,9 +233,11 @@ def test_reduced_precision_modes_against_the_reference_autocast_floor(golden, mo
     assert sdr >= max(floor_db, ref_sdr - 1.0)
 
 
-def test_production_chunk_44s_against_float32_oracle():
+def test_production_chunk_44s_against_float64_oracle():
     """One 44-second item (1 940 400 samples: T = 1 895 frames, 19 BLSTM frames per row at layer 4, 10 at layer 5) -- the
-    chunk `hdemucs_mmi` really runs (remote/hdemucs_mmi.yaml segment: 44) -- sample by sample against the float32 oracle."""
+    chunk `hdemucs_mmi` really runs (remote/hdemucs_mmi.yaml segment: 44) -- sample by sample against the FLOAT64 oracle
+    (itself pinned to the float64 reference to 2e-9 on the goldens).  The float32 oracle's own distance to float64 is
+    printed beside it: that is the noise floor of any float32 evaluation of this network at this length."""
     from demucs_amd.hdemucs_weights import hdemucs_layer_plan
     from oracle import hdemucs_oracle as HO
     cfg = HDemucsConfig()
@@ -247,9 +249,12 @@ def test_production_chunk_44s_against_float32_oracle():
     m.to("cuda")
     mix = torch.from_numpy(synth_mix(90, L, "tones"))[None]
     out = m(mix.cuda()).cpu()
-    osd = {k: torch.from_numpy(v.copy()) for k, v in sd.items()}
+    plan = hdemucs_layer_plan(cfg)
     with torch.no_grad():
-        want = HO.hdemucs_forward(osd, mix, hdemucs_layer_plan(cfg), 4).double()
+        want = HO.hdemucs_forward({k: torch.from_numpy(v.copy()).double() for k, v in sd.items()}, mix.double(), plan, 4)
+        f32 = HO.hdemucs_forward({k: torch.from_numpy(v.copy()) for k, v in sd.items()}, mix, plan, 4).double()
     err = float((out.double() - want).abs().max())
-    print(f"hdemucs 44 s item: max-abs vs the float32 oracle {err:.3e} (out rms {want.pow(2).mean().sqrt():.3f})")
+    floor = float((f32 - want).abs().max())
+    print(f"hdemucs 44 s item: engine vs float64 oracle max-abs {err:.3e}; float32 oracle vs float64 oracle {floor:.3e} "
+          f"(out rms {want.pow(2).mean().sqrt():.3f})")
     assert err <= TOL

@@ -179,28 +179,18 @@ def test_model_rejects_cpu_and_bad_shapes():
         m.forward_segments(torch.zeros(1, 3, SL, device="cuda"))
 
 
-@pytest.mark.skipif(os.environ.get("MI_X6") is not None, reason="already inside the split-bf16 re-run")
-def test_split_bf16_gemm_mode_keeps_parity():
-    """Opt-in mode MI_X6=1 (gemm_x6.hip: fp32 operands as three exact bf16 terms, six bf16 MFMA products, fp32 accumulate):
-    the reference-golden and float64-oracle parity tests above must hold unchanged with the transformer / 1x1 layers on that
-    path.  Re-runs them in a fresh process (the switch is read when the weights are packed); single process, as DESIGN.md
-    section 8 requires for this mode."""
-    env = dict(os.environ, MI_X6="1", MI_X6_MODE="1")
+@pytest.mark.skipif(os.environ.get("MI_X6") is not None or os.environ.get("MI_DCONV_ROW") is not None, reason="already inside the re-run")
+def test_non_default_kernel_switches_keep_parity():
+    """Two opt-in kernel routes, re-run together in ONE fresh process (both switches are read once, at packing / first launch;
+    they touch disjoint layers):
+      * MI_X6=1 (gemm_x6.hip: fp32 operands as three exact bf16 terms, six bf16 MFMA products, fp32 accumulate) on the
+        transformer / 1x1 layers -- single process, as DESIGN.md section 8 requires for this mode;
+      * MI_DCONV_ROW=lds (dconv_row.hip `dconv_rowlds_kernel`: the C = 48 frequency rows stay in LDS across both residual
+        layers; slower than the per-wave kernel, kept selectable).
+    The reference-golden and float64-oracle parity tests above must hold unchanged."""
+    env = dict(os.environ, MI_X6="1", MI_X6_MODE="1", MI_DCONV_ROW="lds")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k",
                         "reference_golden or float64_oracle", "-p", "no:cacheprovider"], env=env, capture_output=True, text=True,
-                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert "passed" in r.stdout
-
-
-@pytest.mark.skipif(os.environ.get("MI_DCONV_ROW") is not None, reason="already inside the re-run")
-def test_lds_resident_dconv_row_keeps_parity():
-    """MI_DCONV_ROW=lds (dconv_row.hip `dconv_rowlds_kernel`: the C = 48 frequency rows stay in LDS across both residual layers,
-    channels split over four waves; slower than the per-wave kernel, kept selectable): the float64-oracle parity test above must
-    hold unchanged with it.  Fresh process: the switch is read at the first launch."""
-    env = dict(os.environ, MI_DCONV_ROW="lds")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k", "float64_oracle",
-                        "-p", "no:cacheprovider"], env=env, capture_output=True, text=True,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "passed" in r.stdout

@@ -93,3 +93,19 @@ def test_bench_multi_gpu_branch_under_torchrun():
     r = json.loads(line)
     assert r["scaling"] == "strong" and r["n_gpus"] == 1 and r["value"] > 200 and "roofline" in r
     assert "RCCL all-gather" in r["config"]["parallelism"]
+
+
+def test_bench_launches_its_own_ranks_without_torchrun():
+    """`python bench.py --gpus N` with NO torchrun environment (the shape of the driver's N = 1 command) must start its ranks
+    itself: a child `torch.distributed.run` started before the parent makes any GPU call, the JSON line relayed, the child's
+    exit code returned.  `--spawn` takes that path with ONE rank (this box has one GPU); `--force-dist` makes the rank run the
+    N > 1 branch (RCCL group, sharded steps, strong-scaling line)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--spawn", "--force-dist", "--seconds", "120", "--steps", "2",
+           "--warmup", "1", "--batch", "16"]
+    p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    r = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert r["scaling"] == "strong" and r["n_gpus"] == 1 and r["value"] > 200
+    ph = r["sharded_step_phases_rank0"]
+    assert ph["calls"] == 2 and ph["segments_ms"] > 0 and ph["all_gather_ms"] >= 0 and ph["stitch_ms"] > 0

@@ -86,5 +86,13 @@ def test_clip_prevention_and_two_stems_match_the_reference(golden):
         audio.prevent_clip(origin, "loud")
     with pytest.raises(KeyError):
         audio.two_stems(origin, stems, "kazoo")
-    with pytest.raises(Exception):
-        audio.prevent_clip(origin.cpu(), "clamp")             # no CPU implementation in this package
+    # host stems (what Separator.separate_tensor(host wav) returns) are staged through the GPU; other float dtypes are cast
+    host = audio.prevent_clip(origin.cpu(), "rescale")
+    assert host.device.type == "cpu" and torch.equal(host, audio.prevent_clip(origin, "rescale").cpu())
+    half = audio.prevent_clip(origin.double(), "clamp")
+    assert half.dtype == torch.float64 and half.is_cuda and float(half.abs().max()) <= 0.99 + 1e-7
+    hs = audio.two_stems(origin.cpu(), {k: v.cpu() for k, v in stems.items()}, "vocals", "add")
+    assert hs["no_vocals"].device.type == "cpu" and torch.equal(hs["no_vocals"], torch.from_numpy(z["two_stems/add/no_vocals"]))
+    bad = origin.clone()
+    bad[0, 5] = float("nan")                                  # torch's abs().max() propagates NaN: so does the device reduction
+    assert bool(torch.isnan(audio.prevent_clip(bad, "rescale")).all())
