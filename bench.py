@@ -512,17 +512,24 @@ def main():
             hm.profile_begin()
             P.apply_model(hbag, hmix, shifts=0, split=True, overlap=0.25, device=dev)
             hrows = hm.profile_end()
-            lstm = [r for r in hrows if r["name"] == "lstm_step_kernel"]
-            BOUNDARY_US = 1.45        # MI355X_MICROARCH.md price list, row "boundary": dependent kernel boundary on one stream
+            lstm = [r for r in hrows if r["name"] in ("lstm_persist_kernel", "lstm_step_kernel")]
+            persist = bool(lstm) and lstm[0]["name"] == "lstm_persist_kernel"
+            # floor of one time step: the persistent kernel (lstm.hip) pays one cross-CU hand-off of the hidden state per step
+            # (MI355X_MICROARCH.md price list, row "handoff-1to1": 0.8-1.0 us on an idle chip); the per-step launch chain of
+            # MI_LSTM_STEPS=1 one dependent kernel boundary (row "boundary": 1.45 us)
+            BOUNDARY_US = 1.0 if persist else 1.45
             h_roof = None
             if lstm:
                 us = lstm[0]["ms"] * 1e3 / lstm[0]["launches"]
-                h_roof = {"bound": "latency", "kernel": "lstm_step_kernel", "launches": lstm[0]["launches"], "avg_launch_us": round(us, 3),
+                h_roof = {"bound": "latency", "kernel": lstm[0]["name"], "time_steps": lstm[0]["launches"], "avg_step_us": round(us, 3),
                           "floor_us": BOUNDARY_US, "frac": round(BOUNDARY_US / us, 4), "chain_ms": round(lstm[0]["ms"], 3),
                           "share_of_step": round(lstm[0]["ms"] * 1e-3 / dt_s, 3),
-                          "note": "main engine's batched forward only (the tail chunk's own 1 600 launches run under it on the side "
-                                  "stream); floor = one dependent kernel boundary per time step; peak / achieved in microseconds per launch",
-                          "achieved": round(us, 3), "peak": BOUNDARY_US, "unit": "us/launch"}
+                          "note": "the BLSTM recurrence of encoder layers 4 / 5: 1 600 DEPENDENT time steps per forward (8 sequences of 200), "
+                                  "main engine's batched forward only (the tail chunk's own chain runs under it on the side stream); "
+                                  + ("ONE persistent launch per sequence, hidden state exchanged between workgroups as tagged granules: floor = "
+                                     "one cross-CU hand-off per step" if persist else "one launch per step: floor = one dependent kernel boundary per step")
+                                  + "; peak / achieved in microseconds per time step",
+                          "achieved": round(us, 3), "peak": BOUNDARY_US, "unit": "us/step"}
             assert o.shape == (1, 4, 2, TRACK_SECONDS * SR) and bool(torch.isfinite(o[0, :, 0, ::997]).all())
             result["modes"]["hdemucs_mmi fp16"] = {"dtype": "f16", "sources": 4, "value": round(TRACK_SECONDS / dt_s, 2), "unit": "audio-sec/wall-sec",
                                                    "ms_per_step": round(dt_s * 1e3, 2), "steps": 3,

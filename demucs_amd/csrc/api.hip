@@ -362,6 +362,15 @@ int mi_lstm_seq(const float *gx_dev, const float *whh_host, int32_t N, int32_t H
         if (r == MI_OK) r = mode ? launch_lstm_persist(gx_dev, wd, N, H, W, out_dev, scratch, flag, st) : launch_lstm_seq(gx_dev, wd, N, H, W, out_dev, state, st);
         fail(hipStreamSynchronize(st), "hipStreamSynchronize");
         if (r == MI_OK && *(volatile unsigned *)flag) r = set_error(MI_EHIP, "mi_lstm_seq: the persistent kernel timed out waiting for its hidden-state exchange");
+        if (r == MI_OK && mode && getenv("MI_LSTM_DEBUG")) {
+                        unsigned dbg[16] = {};
+            (void)hipMemcpy(dbg, (char *)scratch + lstm_persist_ctl_offset(), sizeof(dbg), hipMemcpyDeviceToHost);
+            fprintf(stderr, "[lstm] H %d N %d W %d: block 0 / wave 1 spent %.1f us gathering h in %u poll passes (%.2f us, %.2f passes per step); "
+                    "%s stores\n", H, N, W, dbg[2] * 0.01, dbg[3], dbg[2] * 0.01 / std::max(1, W - 1), (double)dbg[3] / std::max(1, W - 1),
+                    dbg[4] ? "same-XCD plain" : "write-through");
+            fprintf(stderr, "[lstm]   shader cycles per step: gather %.0f, issue + products %.0f, LDS write + barrier %.0f, gate stage %.0f; whole step %.0f\n",
+                    (double)dbg[8] / W, (double)dbg[9] / W, (double)dbg[10] / W, (double)dbg[11] / W, (double)dbg[12] / W);
+        }
     }
     if (wd) (void)hipFree(wd);
     if (state) (void)hipFree(state);

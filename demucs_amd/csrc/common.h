@@ -73,6 +73,25 @@ __device__ __forceinline__ float sigmoid_f(float x) {
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * x));
 }
 
+// LSTM cell update shared by the one-launch-per-step kernel (hkernels.hip) and the persistent kernel (lstm.hip).  The least
+// significant mantissa bit of the returned h is replaced by `tag`: the persistent kernel's workgroups exchange h through memory
+// as self-validating 4-byte values, the bit tells a value of step s from the buffer's previous occupant (step s - 2) -- at most one
+// ulp, applied on both routes so that they agree bit for bit.  lstm_tag flips every second step and is 1 for steps 0 and 1 (a
+// zero-filled buffer is then "not yet written").
+// tanh as v_exp_f32 + v_rcp_f32: (1 - e) / (1 + e) with e = exp(-2 |x|) (each within 1 ulp; absolute error < 2e-7, exact +-1 for
+// large |x|): ~8 instructions against libm tanhf's ~100 with divergent branches -- two of them sat on the critical path of every
+// LSTM time step
+__device__ __forceinline__ float tanh_f(float x) {
+    const float e = __builtin_amdgcn_exp2f(-2.88539008177792681f * fabsf(x));
+    return copysignf((1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e), x);
+}
+__device__ __forceinline__ unsigned lstm_tag(int step) { return (((unsigned)step >> 1) & 1u) ^ 1u; }
+__device__ __forceinline__ float lstm_cell(float ai, float af, float ag, float ao, float &c, unsigned tag) {
+    c = sigmoid_f(af) * c + sigmoid_f(ai) * tanh_f(ag);
+    const float h = sigmoid_f(ao) * tanh_f(c);
+    return __uint_as_float((__float_as_uint(h) & ~1u) | tag);
+}
+
 // two floats -> two bf16 / fp16 values (round to nearest even) in one dword, `a` in the low half
 __device__ __forceinline__ unsigned pack_half2(int dtype, float a, float b) {
     typedef __bf16 pk_bf16x2 __attribute__((ext_vector_type(2)));

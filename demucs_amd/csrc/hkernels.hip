@@ -172,9 +172,8 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const float *__restrict_
 #pragma unroll
         for (int g = 0; g < 4; ++g)
             s4[g] = (part[0][g * RB + gu][gnl] + part[1][g * RB + gu][gnl]) + (part[2][g * RB + gu][gnl] + part[3][g * RB + gu][gnl]);
-        const float ai = pi + s4[0], af = pf + s4[1], ag = pg + s4[2], ao = po + s4[3];
-        const float c = sigmoid_f(af) * pc + sigmoid_f(ai) * tanhf(ag);
-        const float h = sigmoid_f(ao) * tanhf(c);
+        float c = pc;
+        const float h = lstm_cell(pi + s4[0], pf + s4[1], pg + s4[2], po + s4[3], c, lstm_tag(step));
         cst[si] = c;
         hnext[si] = h;
         out[((size_t)gn * 2 * H + dir * H + gj) * W + t] = h;

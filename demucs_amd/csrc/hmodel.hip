@@ -435,13 +435,13 @@ int HModel::hforward_impl(const float *mix, float *out, int B, int L, hipStream_
     const int *Lt = g.Lt, *Lp = g.Lp;
     const mi_ktab_entry *k;
     taps.clear();
-    // MI_H_TWO_STREAMS=1: the waveform branch of layers 0-3 (and of decoder layers 2-5) on the side stream beside the spectral
-    // branch, as in Model::run_core_impl.  OFF by default for this architecture: measured 58.5 ms against 53.3 ms for the
-    // 3-minute track -- the forward is paced by the 1 600 DEPENDENT LSTM step launches of layers 4 / 5, the track's tail chunk
-    // already runs beside the batched forward on its own engine and stream, and more concurrent kernels only lengthen every
-    // step of that chain (5.5-7 -> 8.3 us per launch).
-    static const bool h_two = getenv("MI_H_TWO_STREAMS") != nullptr;
-    const bool two = h_two && side_streams() == MI_OK;
+    // The waveform branch of layers 0-3 (and of decoder layers 2-5) runs on the side stream beside the spectral branch, as in
+    // Model::run_core_impl.  Round 3 measured this schedule SLOWER for this architecture (58.5 against 53.3 ms for the 3-minute
+    // track): the forward was paced by 1 600 dependent LSTM step launches that more concurrent kernels only lengthened.  With the
+    // recurrence in one persistent launch per sequence (lstm.hip) the side stream pays: 37.8-38.1 against 39.3-39.5 ms.
+    // MI_H_ONE_STREAM=1 keeps everything on the caller's stream (A/B, profiling).
+    static const bool h_two = getenv("MI_H_ONE_STREAM") == nullptr;
+    const bool two = h_two && g_two_streams && side_streams() == MI_OK;
     hipStream_t stt = two ? side_st : st;
     auto fork = [&]() -> int {
         if (!two) return MI_OK;
@@ -586,7 +586,9 @@ int HModel::hforward_impl(const float *mix, float *out, int B, int L, hipStream_
     // GLU output (written by the rewrite conv's epilogue, MI_FLAG_IMG) -- and both convs gather their taps by LDS-DMA
     // (gemm_tap.hip) instead of walking a table over float32 tensors.  MI_NO_TAP_IMAGE=1 restores the table-driven route.
     const bool tapimg = cfg.dtype != MI_DTYPE_F32 && x_gimg && hdec[2].rewrite.wtap && htdec[1].rewrite.wtap && hdec[2].convtr.wtap && htdec[1].convtr.wtap;
-    static const bool last_tap = getenv("MI_H_LAST_TAP") != nullptr;       // A/B: the outermost transposed conv (K = 96) on the image route too
+    // the outermost transposed conv (K = 96, bound by its output) on the image route too: no conversion pass is needed here (the GLU
+    // epilogue writes the image), 38.6-38.9 against 39.3-39.5 ms; MI_H_NO_LAST_TAP=1: table-driven gather over float32
+    static const bool last_tap = getenv("MI_H_NO_LAST_TAP") == nullptr;
     MI_TRY(fork());
     if (tapimg) {
         MI_TRY(launch_f32_to_image(x_dec[1], B, 384, (int64_t)8 * Tp, cfg.dtype, x_b, st));

@@ -106,6 +106,7 @@ int launch_lstm_seq(const float *gx, const float *whh /* packed */, int N, int H
 // lstm.hip: the same recurrence as ONE persistent launch per batch of sequence tiles (hidden state exchanged between workgroups
 // as tagged 8-byte granules); scratch: lstm_persist_scratch_bytes() device bytes; ctl_host: pinned host word set on a time-out
 size_t lstm_persist_scratch_bytes();
+size_t lstm_persist_ctl_offset();      // byte offset of the control / debug words inside the scratch block
 int launch_lstm_persist(const float *gx, const float *whh /* packed */, int N, int H, int W, float *out, void *scratch, unsigned *ctl_host,
                         hipStream_t st);
 int launch_local_attn(const float *qkc, int B, int C, int T, int ld /* row pitch of qkc, % 4 == 0 */, float *out, int ld_o, hipStream_t st);
