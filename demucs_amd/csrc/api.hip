@@ -159,6 +159,12 @@ int mi_set_two_streams(int32_t enabled) {
     return old;
 }
 
+int mi_set_istft_fused(int32_t enabled) {
+    const int old = g_istft_fused;
+    g_istft_fused = enabled ? 1 : 0;
+    return old;
+}
+
 int mi_profile_begin(void *handle) {
     if (!handle) return set_error(MI_EINVAL, "mi_profile_begin: null handle");
     ((Model *)handle)->prof.begin();

@@ -278,6 +278,95 @@ __global__ __launch_bounds__(256) void istft_ola_kernel(const float *__restrict_
     out[(size_t)bsc * L + n] = v;
 }
 
+
+// Fused (2) + (3): one workgroup walks a run of consecutive frames of one (b, s) in ascending order, transforms each frame in LDS
+// as istft_frames_kernel does, and keeps the overlap-add of the four hop blocks a frame touches in REGISTERS (thread i owns
+// samples i + 256 q of every 1024-sample hop block, both channels: 32 accumulators).  After frame m has been added, hop block
+// m + 2 holds all four of its frames (m - 3 .. m, added in ascending order: the summation order of istft_ola_kernel, so the two
+// routes agree bit for bit) and goes out: / envelope, crop, + time branch.  The windowed frames (fr: S T 2 4096 floats per
+// item) are never written or re-read: 2.7 GB of the 4.8 GB the two separate kernels move per batched forward; the price is three
+// warm-up frames per run (the blocks they complete belong to the previous run).  The next frame's spectrum is fetched into
+// registers under the current frame's passes.
+// grid (runs, B*S), block 256; run g owns hop blocks [3 + g * R, 3 + (g + 1) * R)
+__global__ __launch_bounds__(256, 2) void istft_fused_kernel(const float *__restrict__ yt, int T, int L, int R, const float *__restrict__ window,
+                                                          const float2 *__restrict__ tw, const float *__restrict__ env,
+                                                          const float *__restrict__ xt, const float2 *__restrict__ denorm_t, int S,
+                                                          int xt_pitch, float *__restrict__ out) {
+    __shared__ float re[kLdsN], im[kLdsN], twr[kN / 2], twi[kN / 2];
+    const int i = threadIdx.x, bs = blockIdx.y;
+    const int hb0 = 3 + blockIdx.x * R, hb_last = (L - 1 + 3584) >> 10;        // first block of this run, last block of the signal
+    const int hb1 = min(hb0 + R, hb_last + 1);
+    if (hb0 > hb_last) return;
+    stage_twiddles(tw, twr, twi, i);
+    float ev[4];                              // this thread's envelope samples
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ev[q] = env[i + 256 * q];
+    float2 dn = make_float2(0.f, 1.f);
+    if (xt) dn = denorm_t[bs / S];
+    float acc[4][4][2];                       // [segment j = hop block m + 2 + j][sample i + 256 q][channel]
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[j][q][0] = acc[j][q][1] = 0.f;
+    const int m_first = hb0 - 5, m_last = hb1 - 3;           // frames that touch blocks [hb0, hb1): block hb takes frames hb - 5 .. hb - 2
+#pragma unroll 1
+    for (int m = m_first; m <= m_last; ++m) {
+        const bool live = m >= 0 && m < T;                   // workgroup-uniform: frames outside the data are the zero pad
+        if (live) {
+            const float *src = yt + ((size_t)bs * T + m) * 4 * kBins;
+            __syncthreads();                                 // the previous frame's last LDS reads are done (and the twiddles staged)
+            // (two workgroups share a CU: the other one covers this frame's loads; a register prefetch of the next
+            // frame cost 32 VGPRs and a spill at two workgroups per CU)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int k = i + 256 * r;
+                float ar = src[k], ai = src[kBins + k], br = src[2 * kBins + k], bi = src[3 * kBins + k];
+                if (k == 0) { ai = 0.f; bi = 0.f; }
+                re[lpad(k)] = ar - bi; im[lpad(k)] = ai + br;
+                if (k > 0) { re[lpad(kN - k)] = ar + bi; im[lpad(kN - k)] = br - ai; }
+            }
+            if (i == 0) { re[lpad(kBins)] = 0.f; im[lpad(kBins)] = 0.f; }
+            __syncthreads();
+            cf u[16];
+            load_pass_input<true>(u, i, re, im);
+            __syncthreads();
+            stockham_pass<true, 1>(u, i, re, im, twr, twi);
+            fft_tail<true>(u, i, re, im, twr, twi);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {                   // sample p = i + 256 r: segment r / 4, offset i + 256 (r % 4)
+                const int p = i + 256 * r;
+                const float w = window[p] * (1.0f / 64.0f);          // L1 / L2 hit: 16 KB shared by every workgroup
+                acc[r >> 2][r & 3][0] += re[lpad(p)] * w;
+                acc[r >> 2][r & 3][1] += im[lpad(p)] * w;
+            }
+        }
+        const int hb = m + 2;                                // complete now
+        if (hb >= hb0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = hb * 1024 + i + 256 * q - 3584;
+                if (n >= 0 && n < L) {
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        float v = acc[0][q][c] / ev[q];
+                        const size_t row = (size_t)bs * 2 + c;
+                        if (xt) v += xt[row * xt_pitch + n] * dn.y + dn.x;
+                        out[row * L + n] = v;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                acc[0][q][c] = acc[1][q][c]; acc[1][q][c] = acc[2][q][c]; acc[2][q][c] = acc[3][q][c]; acc[3][q][c] = 0.f;
+            }
+    }
+}
+
+int g_istft_fused = getenv("MI_ISTFT_SPLIT") == nullptr ? 1 : 0;
+
 // ---------------------------------------------------------------------------------------------
 // host-side launchers
 // ---------------------------------------------------------------------------------------------
@@ -304,6 +393,18 @@ int launch_istft(const float *y, int B, int S, int L, const float2 *denorm, cons
     const int T = ceil_div(L, kHop);
     hipLaunchKernelGGL(spec_transpose_kernel, dim3(ceil_div(T, 32), kBins / 32, B * S * 4), dim3(256), 0, st, y, T, S * 4, denorm, yt, y_pitch ? y_pitch : T);
     MI_CHECK_LAUNCH();
+    // default: the fused frame + overlap-add kernel; MI_ISTFT_SPLIT=1 / mi_set_istft_fused(0): the two separate kernels (A/B, and
+    // the bit-identity test of the fused one)
+    if (g_istft_fused) {
+        const int blocks = ((L - 1 + 3584) >> 10) - 2;               // hop blocks 3 .. last
+        // runs of ~43 blocks (three warm-up frames per run: 7 % more transforms) while that still fills the chip
+        const int runs = std::max(1, std::min(ceil_div(blocks, 12), std::max(ceil_div(blocks, 43), ceil_div(1024, B * S))));
+        const int R = ceil_div(blocks, runs);
+        hipLaunchKernelGGL(istft_fused_kernel, dim3(ceil_div(blocks, R), B * S), dim3(256), 0, st, yt, T, L, R, tb.window, tb.twiddle, tb.envelope, xt,
+                           denorm_t, S, xt_pitch ? xt_pitch : L, out);
+        MI_CHECK_LAUNCH();
+        return MI_OK;
+    }
     hipLaunchKernelGGL(istft_frames_kernel, dim3(T, B * S), dim3(256), 0, st, yt, T, tb.window, tb.twiddle, fr);
     MI_CHECK_LAUNCH();
     hipLaunchKernelGGL(istft_ola_kernel, dim3(ceil_div(L, 256), B * S * 2), dim3(256), 0, st, fr, T, L, tb.envelope, xt, denorm_t, S, xt_pitch ? xt_pitch : L, out);

@@ -48,6 +48,9 @@ struct HModel : Model {
     float *x_dh = nullptr, *x_dy1 = nullptr, *x_dy2 = nullptr, *x_dy3 = nullptr, *x_xf = nullptr, *x_gx = nullptr, *x_o0 = nullptr,
           *x_o1 = nullptr, *x_xl = nullptr, *x_qkc = nullptr, *x_att = nullptr, *x_lstm = nullptr;
     float *x_dec[6] = {}, *x_tdec[5] = {}, *x_yt = nullptr, *x_fr = nullptr;
+    float *x_eimg[2][3] = {};         // half modes: phase-split operand images of the encoder outputs 0..2 ([branch][level]); slots the
+    size_t x_eimg_floats[2][3] = {};  // epilogues never write are the convs' zero padding: re-zeroed when the geometry changes
+    int eimg_L = -1, eimg_B = -1;     // geometry the images' zero slots are valid for
     float *x_gimg = nullptr, *x_tgimg = nullptr;      // half modes: 16-bit operand images of the decoders' GLU outputs (hmodel.hip)
     double *x_stats = nullptr, *x_stats_t = nullptr;
     float2 *x_st1 = nullptr, *x_st2 = nullptr, *x_st1t = nullptr, *x_st2t = nullptr, *x_nf = nullptr, *x_df = nullptr, *x_nt = nullptr,

@@ -128,11 +128,13 @@ int HModel::hinit(const mi_config &c, const mi_tensor_desc *weights, size_t n) {
         MI_TRY(wt.get(p + ".conv.weight", (int64_t)C * Cin * 8, &w)); MI_TRY(wt.get(p + ".conv.bias", C, &b));
         MI_TRY(wt.get(p + ".rewrite.weight", (int64_t)2 * C * C, &rw)); MI_TRY(wt.get(p + ".rewrite.bias", 2 * C, &rb));
         MI_TRY(pack_conv(w, b, C, Cin * 8, false, &henc[i].conv));
+        if (i) MI_TRY(pack_enc_tap(w, Cin, &henc[i].conv));        // half modes: stride-1 two-tap form over a phase-split image
         MI_TRY(pack_conv(rw, rb, 2 * C, C, true, &henc[i].rewrite));
         MI_TRY(load_dconv(wt, p, C, 1, 1, true, &henc[i].dconv, 4));
         MI_TRY(wt.get(pt + ".conv.weight", (int64_t)C * Cint * 8, &w)); MI_TRY(wt.get(pt + ".conv.bias", C, &b));
         MI_TRY(wt.get(pt + ".rewrite.weight", (int64_t)2 * C * C, &rw)); MI_TRY(wt.get(pt + ".rewrite.bias", 2 * C, &rb));
         MI_TRY(pack_conv(w, b, C, Cint * 8, false, &htenc[i].conv));
+        if (i) MI_TRY(pack_enc_tap(w, Cint, &htenc[i].conv));
         MI_TRY(pack_conv(rw, rb, 2 * C, C, true, &htenc[i].rewrite));
         MI_TRY(load_dconv(wt, pt, C, 1, 1, false, &htenc[i].dconv, 4));
     }
@@ -210,7 +212,14 @@ int HModel::hinit(const mi_config &c, const mi_tensor_desc *weights, size_t n) {
     }
     MI_TRY(A(&x_skip[4], 768 * T)); MI_TRY(A(&x_skip[5], 1536 * T5)); MI_TRY(A(&x_inject, 768 * T));
     MI_TRY(A(&x_a, big)); MI_TRY(A(&x_b, big)); MI_TRY(A(&x_h, big / 2)); MI_TRY(A(&x_ta, big)); MI_TRY(A(&x_tb, big)); MI_TRY(A(&x_th, big / 2));
-    if (c.dtype != MI_DTYPE_F32) { MI_TRY(A(&x_gimg, big / 2)); MI_TRY(A(&x_tgimg, big / 2)); }   // half modes: operand images of the decoders' GLU outputs
+    if (c.dtype != MI_DTYPE_F32) {
+        MI_TRY(A(&x_gimg, big / 2)); MI_TRY(A(&x_tgimg, big / 2));         // half modes: operand images of the decoders' GLU outputs
+        for (int i = 0; i < 3; ++i) {            // ... and phase-split images of the encoder outputs 0..2 (gemm_conv.h MI_FLAG_IMG4)
+            const size_t pqf = (size_t)(hFr[i + 1] / 4 + 1) * T, pqt = round_up(ceil_div(lt[i + 1], 4) + 1, 4);
+            x_eimg_floats[0][i] = (2 * hCh[i] * pqf + 64) * B; x_eimg_floats[1][i] = (2 * hCh[i] * pqt + 64) * B;
+            MI_TRY(A(&x_eimg[0][i], 2 * hCh[i] * pqf)); MI_TRY(A(&x_eimg[1][i], 2 * hCh[i] * pqt));
+        }
+    }
     MI_HIP(hipMemset(x_h, 0, (big / 2 + 64) * B * sizeof(float)));        // hidden tensors carry zero padding channels
     MI_HIP(hipMemset(x_th, 0, (big / 2 + 64) * B * sizeof(float)));
     const size_t zsz = std::max<size_t>(3072 * (T5 + 2), std::max<size_t>(3072 * T + 64, 384 * (4 * T + 8)));   // largest: decoder.1's 384 x 8 x T
@@ -464,6 +473,17 @@ int HModel::hforward_impl(const float *mix, float *out, int B, int L, hipStream_
     MI_TRY(launch_finalize_stats(x_stats, B, 4.0 * 2048 * T, 1e-5f, 1, x_nf, x_df, st));
     MI_TRY(launch_cac_transpose(x_zt, B, T, x_nf, x_0, st, Tp));
     // ---- encoder layers 0-3, both branches ------------------------------------------------------------------------
+    // Half modes: a level's output feeds the next level's strided conv (k = 8, s = 4, pad 2) as a PHASE-SPLIT 16-bit image written by
+    // the 1x1 + GLU epilogue beside the float32 skip tensor (gemm_conv.h MI_FLAG_IMG4); the conv is then a stride-1 two-tap conv
+    // whose taps gemm_tap.hip fetches by LDS-DMA.  The image slots no epilogue writes are the conv's zero padding: they depend
+    // on the geometry (length, batch), so the images are re-zeroed when it changes.
+    const bool encimg = cfg.dtype != MI_DTYPE_F32 && x_eimg[0][0] && henc[1].conv.wtap && htenc[1].conv.wtap;
+    if (encimg && (eimg_L != L || eimg_B != B)) {
+        for (int br = 0; br < 2; ++br)
+            for (int i = 0; i < 3; ++i) MI_HIP(hipMemsetAsync(x_eimg[br][i], 0, x_eimg_floats[br][i] * sizeof(float), st));
+        eimg_L = L; eimg_B = B;
+        MI_TRY(fork());                        // the side stream starts behind the re-zeroing
+    }
     const float *xf = x_0, *xt = x_t0;
     for (int i = 0; i < 4; ++i) {
         const int Cin = i ? hCh[i - 1] : 4, Cint = i ? hCh[i - 1] : 2, C = hCh[i];
@@ -474,11 +494,20 @@ int HModel::hforward_impl(const float *mix, float *out, int B, int L, hipStream_
             mi_conv_desc d = base_desc(htenc[i].conv, k, xt, (int64_t)Cint * Lp[i], gin);
             d.O2 = Lp[i + 1]; d.o2_valid = Lt[i + 1]; d.S2 = 4; d.epi = MI_EPI_LINEAR; d.flags = MI_FLAG_GELU;
             d.y = x_ta; d.y_bstride = C * P; d.y_cstride = P;
+            if (i && encimg) {                 // the previous level's output as a phase-split image: slots o2, o2 + 1 of every plane
+                const int Qp = round_up(ceil_div(Lt[i], 4) + 1, 4);
+                d.xh = x_eimg[1][i - 1]; d.xh_n = (int64_t)B * Qp; d.wtap = htenc[i].conv.wtap; d.ntaps = 2; d.tap_k2 = 2;
+                d.D2 = Qp; d.x_ld = Qp; d.S2 = 1;
+            }
             MI_TRY(conv(d, stt));
             MI_TRY(run_dconv(g.tenc_dconv[i], C, go, x_ta, x_tb, x_th, x_stats_t, x_st1t, x_st2t, stt, w_gram2_t, gram2t_bytes));
             MI_TRY(ktab(g, Gather{C, 1, 1, 1, 1, 0, 0, P, (int)P}, htenc[i].rewrite.Kpad, &k));
             mi_conv_desc r = base_desc(htenc[i].rewrite, k, x_ta, C * P, go);
             r.plain = 1; r.epi = MI_EPI_GLU; r.y = x_skip_t[i]; r.y_bstride = C * P; r.y_cstride = P;
+            if (i < 3 && encimg) {
+                const int64_t pq = round_up(ceil_div(Lt[i + 1], 4) + 1, 4);
+                r.flags |= MI_FLAG_IMG4; r.yh = x_eimg[1][i]; r.yh_pq = pq; r.yh_n = (int64_t)B * pq;
+            }
             MI_TRY(conv(r, stt));
             xt = x_skip_t[i];
             taps["tenc" + std::to_string(i)] = {x_skip_t[i], C * P};
@@ -490,12 +519,21 @@ int HModel::hforward_impl(const float *mix, float *out, int B, int L, hipStream_
             mi_conv_desc d = base_desc(henc[i].conv, k, xf, Cin * Pin, gin);
             d.O1 = hFr[i + 1]; d.S1 = 4; d.epi = MI_EPI_LINEAR; d.flags = MI_FLAG_GELU;
             d.y = x_a; d.y_bstride = C * P; d.y_cstride = P;
+            if (i && encimg) {                 // rows o1, o1 + 1 of every plane of the previous level's image
+                const int Q = hFr[i] / 4 + 1;
+                d.xh = x_eimg[0][i - 1]; d.xh_n = (int64_t)B * Q * Tp; d.wtap = henc[i].conv.wtap; d.ntaps = 2; d.tap_k2 = 1;
+                d.D1 = Q; d.S1 = 1;
+            }
             MI_TRY(conv(d, st));
             MI_TRY(run_dconv(g.enc_dconv[i], C, go, x_a, x_b, x_h, x_stats, x_st1, x_st2, st));
             MI_TRY(ktab(g, Gather{C, 1, 1, 1, 1, 0, 0, P, Tp}, henc[i].rewrite.Kpad, &k));
             mi_conv_desc r = base_desc(henc[i].rewrite, k, x_a, C * P, go);
             r.plain = 1; r.epi = MI_EPI_GLU; r.y = x_skip[i]; r.y_bstride = C * P; r.y_cstride = P;
             if (i == 0) { r.flags = MI_FLAG_EMB; r.emb = freq_emb; }
+            if (i < 3 && encimg) {
+                const int64_t pq = (int64_t)(hFr[i + 1] / 4 + 1) * Tp;
+                r.flags |= MI_FLAG_IMG4 | MI_FLAG_TR_FREQ; r.yh = x_eimg[0][i]; r.yh_pq = pq; r.yh_n = (int64_t)B * pq;
+            }
             MI_TRY(conv(r, st));
             xf = x_skip[i];
             taps["enc" + std::to_string(i)] = {x_skip[i], C * P};

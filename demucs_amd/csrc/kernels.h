@@ -20,6 +20,8 @@ int launch_istft(const float *y, int B, int S, int L, const float2 *denorm, cons
                  const FftTables &tb, float *yt, float *fr, float *out, hipStream_t st, int xt_pitch = 0 /* row pitch of xt, 0 = L */,
                  int y_pitch = 0 /* row pitch of y along T, 0 = T */);
 
+extern int g_istft_fused;      // fft.hip: 1 = fused inverse-transform + overlap-add kernel (default), 0 = the two separate kernels
+
 // norms.hip
 int launch_row_stats(const float *x, int rows, int64_t count, int64_t row_stride, double *stats, hipStream_t st);
 int launch_finalize_stats(double *stats, int rows, double count, float eps, int mode, float2 *out_a, float2 *out_b,

@@ -109,6 +109,11 @@ typedef struct mi_profile_row {
  *   (enabled = 1, the default: results are bit-identical either way); 0 keeps every launch on the caller's stream, one kernel on
  *   the GPU at a time -- what a per-kernel timing wants.  Returns the previous setting.  Process-wide. */
 int mi_set_two_streams(int32_t enabled);
+/* mi_set_istft_fused: the inverse STFT (demucs/spec.py:30-47) runs its per-frame inverse transforms and the overlap-add in ONE
+ *   kernel (hop blocks accumulated in registers; the windowed frames never go to memory).  0 selects the two separate kernels
+ *   (frames to memory, then a gather): same summation order, bit-identical output -- kept for A/B runs and as the check of the
+ *   fused kernel.  Process-wide; returns the previous setting.  Initial value: 1 unless MI_ISTFT_SPLIT is set. */
+int mi_set_istft_fused(int32_t enabled);
 int mi_profile_begin(void *handle);
 int mi_profile_end(void *handle, mi_profile_row *rows, int32_t max_rows, int32_t *n_rows, void *stream);
 

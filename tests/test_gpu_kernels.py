@@ -85,6 +85,25 @@ def test_istft_matches_oracle_and_roundtrip(lib):
     assert (back.double() - oracle_rt).abs().max().item() < 5e-6
 
 
+@pytest.mark.parametrize("L", [SL, 44100 * 3 + 17, 5000, 1023 * 7])
+def test_fused_istft_is_bit_identical_to_the_separate_kernels(lib, L):
+    """The default inverse STFT keeps the overlap-add of a run of frames in registers (istft_fused_kernel); the two separate
+    kernels (frames to memory, then a gather) add the same four frames per sample in the same ascending order: equal bits, at
+    the segment length, at lengths that are no multiple of the hop and at a short input."""
+    T = -(-L // 1024)
+    x = rnd(2, 3, 4, 2048, T, seed=5).float().cuda()
+    outs = []
+    for fused in (1, 0):
+        old = lib.mi_set_istft_fused(fused)
+        try:
+            out = torch.full((2, 3, 2, L), float("nan"), device="cuda")
+            _lib.check(lib.mi_istft_cac(x.data_ptr(), 2, 3, L, out.data_ptr(), stream()), "mi_istft_cac")
+        finally:
+            lib.mi_set_istft_fused(old)
+        outs.append(out.cpu())
+    assert bool(torch.isfinite(outs[0]).all()) and torch.equal(outs[0], outs[1])
+
+
 # ------------------------------------------------------------------------------------------------
 from gpu_helpers import (EPI_BIAS_STATS, EPI_CONVTR, EPI_GLU, EPI_GN_GLU, EPI_LINEAR, EPI_STATS_ONLY, FLAG_EMB,  # noqa: E402
                          FLAG_GELU, FLAG_RES, FLAG_SCALE, FLAG_TR_FREQ, SLOTS, conv_call, ktab, maxerr, pack_vec, pack_w)
