@@ -172,9 +172,15 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     multi = world > 1 or args.force_dist
+    saved_stdout = None
     if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
+        # RCCL prints its version banner on STDOUT when a communicator is created: until the warm-up steps are over (every
+        # communicator exists by then) file descriptor 1 points at stderr, so that stdout carries nothing but the JSON line
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
         dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
     if args.force_dist:
         from demucs_amd import distributed as _dd
@@ -215,7 +221,13 @@ def main():
     out = None
     for _ in range(args.warmup):
         out = step(mix)
+    if multi and args.warmup == 0:
+        dist.barrier()                       # creates the communicator (and prints its banner) before stdout is restored
     fence()
+    if saved_stdout is not None:
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
     model.profile_begin()
     import contextlib
     from demucs_amd import distributed as _dd

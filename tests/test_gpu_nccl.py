@@ -105,7 +105,9 @@ def test_bench_launches_its_own_ranks_without_torchrun():
            "--warmup", "1", "--batch", "16"]
     p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
-    r = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), lines[:5]      # stdout is the ONE JSON line (RCCL's banner goes to stderr)
+    r = json.loads(lines[0])
     assert r["scaling"] == "strong" and r["n_gpus"] == 1 and r["value"] > 200
     ph = r["sharded_step_phases_rank0"]
     assert ph["calls"] == 2 and ph["segments_ms"] > 0 and ph["all_gather_ms"] >= 0 and ph["stitch_ms"] > 0
