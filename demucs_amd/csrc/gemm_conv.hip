@@ -236,6 +236,160 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_dma_kernel(const mi_conv_des
 }
 
 // ---------------------------------------------------------------------------------------------
+// LDS-DMA main loop for STRIDE-1 k x k convolutions in float32 (the decoders' 3 x 3 / k = 3 "rewrite" convs, reference
+// demucs/hdemucs.py:304-314): round 3 ran them on the table-driven gather of conv_gemm_kernel (8 dword gathers + bounds tests
+// + ds_writes per thread and K step) at 0.64-0.70 of the fp32 MFMA peak against 0.74 for the DMA loop above.  Row k = (ci, tap)
+// of a K step's B tile is, for 128 consecutive output positions, a run of the input row shifted by the tap's offset
+// d1 * pitch + d2 -- and global_load_lds_dwordx4 takes a source that is only 4-byte aligned (tools/micro/dma_unaligned.hip), so
+// the run goes global -> LDS by DMA like a plain layer's: no staging registers, no table.  What the shift drags in at the two
+// ends of an input row (the neighbouring row's sample, or a pitch-padding column) is overwritten with the conv's zero padding
+// in LDS by the lane that issued the transfer, after its counted wait and before the barrier: at most two ds_write_b32 per
+// lane and K step.  Taps whose input ROW lies outside the frame read the zero page.  K2 = 3 (|d2| <= 1).
+// Tiles: 128 x 128 (2 x 2 waves) and 96 x 128 (1 x 4 waves; the A image [16][96] is six 1-KiB transfers: waves 0, 1 issue two
+// of them, waves 2, 3 one, so the counted waits are per wave).  Same 3-stage ring, one raw s_barrier per K step.
+template <int BMT, int EPI, int NT>
+__global__ __launch_bounds__(256, 3) void conv_gemm_dmatap_kernel(const mi_conv_desc d, const int N, const int MT, const int Gm) {
+    constexpr int BM = BMT, WM = BM == 128 ? 2 : 1, WN = 4 / WM, TM = BM / (32 * WM), TN = BN / (32 * WN);
+    constexpr int SS = BK * (BM + BN);                       // floats per stage: A image then B image
+    __shared__ __attribute__((aligned(16))) float smem[3 * SS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    int mt, nt;
+    if (!tile_of_block(MT, Gm, N, mt, nt)) return;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int P = d.O1 * d.O2;
+    const int o2v = d.o2_valid ? d.o2_valid : d.O2;
+    constexpr int K2 = 3;                                    // NT = 9 (3 x 3) or 3 (k = 3): divisions by constants
+    const int x_ld = d.x_ld ? d.x_ld : d.D2;
+    const int64_t chan = (int64_t)d.D1 * x_ld;               // input channel stride
+    const float *zero = d.sink + 256;
+
+    // ---- A: this wave's transfers of every K step ------------------------------------------------------------------------------
+    // BM = 128: two transfers of two 128-float rows each (rows 4 wave + 2 j + (lane >> 5)); BM = 96: transfer q moves floats
+    // [256 q, 256 q + 256) of the [16][96] image, q = wave and, for waves 0 and 1, q = 4 + wave
+    constexpr int NA = BM == 128 ? 2 : 2;                    // slots (the second one of waves 2, 3 is idle at BM = 96)
+    const bool a2 = BM == 128 || wave < 2;
+    int a_row[NA], a_col[NA], a_lds[NA];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+        if (BM == 128) { a_row[j] = 4 * wave + 2 * j + (lane >> 5); a_col[j] = (lane & 31) * 4; a_lds[j] = (4 * wave + 2 * j) * BM; }
+        else { const int q = j ? 4 + wave : wave, f = 256 * q + 4 * lane; a_row[j] = f / 96; a_col[j] = f % 96; a_lds[j] = 256 * q; }
+    }
+    // ---- B: rows 4 wave + 2 j + (lane >> 5), 16 bytes at column 4 (lane & 31) ---------------------------------------------------
+    const int c4 = (lane & 31) * 4, rb0 = 4 * wave + (lane >> 5);
+    const ColInfo lc = decompose(n0 + c4, N, P, d.O2, o2v);
+    const float *xcol = d.x + (size_t)lc.b * d.x_bstride + (size_t)lc.o1 * x_ld + lc.o2;
+    // elements of this lane's 4-column chunk that a tap with d2 = -1 / +1 reads from outside the input row [0, D2)
+    const int fix_l = (lc.valid && lc.o2 == 0) ? 0 : -1;
+    const int fr = d.D2 - 1 - lc.o2;
+    const int fix_r = (lc.valid && fr >= 0 && fr < 4) ? fr : -1;
+
+#define MI_TAPDMA_TILE(kt, stage)                                                                                   \
+    do {                                                                                                            \
+        float *sa = smem + (stage) * SS, *sb = sa + BK * BM + (4 * wave) * BN;                                      \
+        _Pragma("unroll") for (int j = 0; j < NA; ++j)                                                              \
+            if (j == 0 || a2) {                                                                                     \
+                const float *ga = d.wt + (size_t)((kt) * BK + a_row[j]) * d.Mpad + m0 + a_col[j];                   \
+                __builtin_amdgcn_global_load_lds((gvoid_t *)ga, (lvoid_t *)(sa + a_lds[j]), 16, 0, 0);              \
+            }                                                                                                       \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                             \
+            const int k = (kt) * BK + rb0 + 2 * j, ci = k / NT, tap = k - ci * NT, t1 = tap / K2, t2 = tap - t1 * K2; \
+            const int i1 = lc.o1 + t1 - d.tap_pad1;                                                                 \
+            const bool ok = lc.valid && k < d.K && (unsigned)i1 < (unsigned)d.D1;                                   \
+            const float *gb = xcol + (int64_t)ci * chan + (int64_t)(t1 - d.tap_pad1) * x_ld + (t2 - d.tap_pad2);    \
+            __builtin_amdgcn_global_load_lds((gvoid_t *)(ok ? gb : zero), (lvoid_t *)(sb + 2 * j * BN), 16, 0, 0);  \
+        }                                                                                                           \
+    } while (0)
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int nk = d.Kpad / BK;
+    const int li = lane & 31, lh = lane >> 5;
+    MI_TAPDMA_TILE(0, 0);
+    if (nk > 1) MI_TAPDMA_TILE(1, 1);
+    int stage = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        // tile kt has landed once all but this wave's newest tile (4 transfers; 3 for waves 2, 3 of the 96-row tile) are done
+        if (kt + 1 < nk) {
+            if (a2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        {   // the conv's zero padding at the ends of the input rows, in the rows this lane transferred
+            float *sb = smem + stage * SS + BK * BM + (4 * wave) * BN + (lane >> 5) * BN + c4;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int k = kt * BK + rb0 + 2 * j, tap = k % NT, dd2 = tap % K2 - d.tap_pad2;
+                if (dd2 < 0 && fix_l >= 0) sb[2 * j * BN + fix_l] = 0.f;
+                if (dd2 > 0 && fix_r >= 0) sb[2 * j * BN + fix_r] = 0.f;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        // stage (kt+2)%3 == (kt-1)%3 was last read in the previous iteration, which every wave has finished
+        if (kt + 2 < nk) MI_TAPDMA_TILE(kt + 2, stage == 0 ? 2 : stage - 1);
+        const float *As = smem + stage * SS, *Bs = As + BK * BM;
+        float af[2][TM], bf[2][TN];
+#pragma unroll
+        for (int a = 0; a < TM; ++a) af[0][a] = As[lh * BM + (wm * TM + a) * 32 + li];
+#pragma unroll
+        for (int b = 0; b < TN; ++b) bf[0][b] = Bs[lh * BN + (wn * TN + b) * 32 + li];
+#pragma unroll
+        for (int s = 0; s < BK / 2; ++s) {
+            if (s + 1 < BK / 2) {
+#pragma unroll
+                for (int a = 0; a < TM; ++a) af[(s + 1) & 1][a] = As[(2 * (s + 1) + lh) * BM + (wm * TM + a) * 32 + li];
+#pragma unroll
+                for (int b = 0; b < TN; ++b) bf[(s + 1) & 1][b] = Bs[(2 * (s + 1) + lh) * BN + (wn * TN + b) * 32 + li];
+            }
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s & 1][a], bf[s & 1][b], acc[a][b], 0, 0, 0);
+        }
+        constexpr int kReads = (TM == 2 ? 1 : TM) + (TN == 2 ? 1 : TN);
+        __builtin_amdgcn_sched_group_barrier(0x100, kReads, 0);
+#pragma unroll
+        for (int s = 0; s < BK / 2; ++s) {
+            if (s + 1 < BK / 2) __builtin_amdgcn_sched_group_barrier(0x100, kReads, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
+        }
+        stage = stage == 2 ? 0 : stage + 1;
+    }
+#undef MI_TAPDMA_TILE
+    conv_epilogue<TM, TN, EPI, 0>(d, acc, m0, n0, wm, wn, N, P, o2v);
+}
+
+// float32, stride-1 k x k conv with K2 = 3 whose geometry the descriptor states (ntaps, tap_k2, tap_pad*): the DMA loop above
+static bool dmatap_eligible(const mi_conv_desc &d, int tile) {
+    static const bool off = getenv("MI_NO_DMA_TAP") != nullptr;
+    const int ld = d.x_ld ? d.x_ld : d.D2;
+    return !off && !d.half && !d.wx && d.epi == MI_EPI_GLU && (tile == 96 || tile == 128) && (d.ntaps == 9 || d.ntaps == 3) && d.tap_k2 == 3 &&
+           d.K % d.ntaps == 0 && d.S1 == 1 && d.S2 == 1 && d.O1 == d.D1 && d.O2 == ld && ld % 4 == 0 && d.tap_pad2 == 1 &&
+           d.tap_pad1 == (d.ntaps / 3 - 1) / 2 && !(d.flags & (MI_FLAG_IMG | MI_FLAG_IMG4)) && d.x_bstride == (int64_t)(d.K / d.ntaps) * d.D1 * ld;
+}
+template <int EPI>
+static int launch_dmatap(const mi_conv_desc &d, int tile, hipStream_t st) {
+    const int64_t N64 = (int64_t)d.B * d.O1 * d.O2;
+    MI_REQUIRE(N64 < (1ll << 31) - 256 && d.Mpad % tile == 0, "conv: DMA tap route: %lld positions, Mpad %d", (long long)N64, d.Mpad);
+    const int N = (int)N64, MT = d.Mpad / tile, NT = ceil_div(N, BN);
+    const unsigned grid = grouped_grid(MT, NT, 1);
+    if (tile == 128 && d.ntaps == 9) hipLaunchKernelGGL((conv_gemm_dmatap_kernel<128, EPI, 9>), dim3(grid), dim3(256), 0, st, d, N, MT, 1);
+    else if (tile == 128) hipLaunchKernelGGL((conv_gemm_dmatap_kernel<128, EPI, 3>), dim3(grid), dim3(256), 0, st, d, N, MT, 1);
+    else if (d.ntaps == 9) hipLaunchKernelGGL((conv_gemm_dmatap_kernel<96, EPI, 9>), dim3(grid), dim3(256), 0, st, d, N, MT, 1);
+    else hipLaunchKernelGGL((conv_gemm_dmatap_kernel<96, EPI, 3>), dim3(grid), dim3(256), 0, st, d, N, MT, 1);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 template <int WM, int WN, int TM, int TN, int EPI, int LFLAGS, bool PLAIN>
 static int launch_cfg(const mi_conv_desc &d, hipStream_t st) {
     constexpr int BM = WM * TM * 32;
@@ -421,6 +575,7 @@ int launch_conv(const mi_conv_desc &din, hipStream_t st) {
                "conv: MI_FLAG_HEADS needs a half-precision LINEAR layer on tokens (O1 = 1) with M %% 512 == 0 and an aligned output");
     MI_REQUIRE(!d.xh || d.half, "conv: an operand-image input needs a half-precision layer");
     if (d.half) return launch_conv_half(d, tile, plain, st);
+    if (!plain && dmatap_eligible(d, tile)) return launch_dmatap<MI_EPI_GLU>(d, tile, st);
     static const int x6_mode = getenv("MI_X6_MODE") ? atoi(getenv("MI_X6_MODE")) : 0;   // bisecting: 1 plain only, 2 gather only
     static const int x6_class = getenv("MI_X6_CLASS") ? atoi(getenv("MI_X6_CLASS")) : -1;   // bisecting: one kernel class only
     if (x6_class >= 0 && x6_class != d.epi * 8 + (tile == 32 ? 0 : tile == 64 ? 1 : tile == 96 ? 2 : 3) * 2 + (plain ? 1 : 0)) d.wx = nullptr;

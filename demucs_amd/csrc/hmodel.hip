@@ -233,10 +233,13 @@ int HModel::hinit(const mi_config &c, const mi_tensor_desc *weights, size_t n) {
     MI_TRY(halloc(&x_lstm_scratch, lstm_persist_scratch_bytes()));
     MI_HIP(hipHostMalloc((void **)&lstm_timeout, 64, hipHostMallocMapped));
     *lstm_timeout = 0;
-    MI_TRY(A(&x_dec[0], 768 * T)); MI_TRY(A(&x_dec[1], 384 * 8 * T)); MI_TRY(A(&x_dec[2], 192 * 32 * T)); MI_TRY(A(&x_dec[3], 96 * 128 * T));
-    MI_TRY(A(&x_dec[4], 48 * 512 * T)); MI_TRY(A(&x_dec[5], (size_t)4 * S * 2048 * T));
-    MI_TRY(A(&x_tdec[0], (size_t)384 * lp[4])); MI_TRY(A(&x_tdec[1], (size_t)192 * lp[3])); MI_TRY(A(&x_tdec[2], (size_t)96 * lp[2]));
-    MI_TRY(A(&x_tdec[3], (size_t)48 * lp[1])); MI_TRY(A(&x_tdec[4], (size_t)2 * S * lp[0]));
+    // (the decoder inputs carry 128 bytes of slack in front as well: the float32 k x k convs read them by LDS-DMA in runs shifted
+    // by one sample, gemm_conv.hip conv_gemm_dmatap_kernel; A() already leaves 64 floats per item behind)
+    auto AS = [&](float **p, size_t per_item) { const int r = halloc((void **)p, ((per_item + 64) * B + 64) * sizeof(float)); if (r == MI_OK) *p += 32; return r; };
+    MI_TRY(A(&x_dec[0], 768 * T)); MI_TRY(AS(&x_dec[1], 384 * 8 * T)); MI_TRY(AS(&x_dec[2], 192 * 32 * T)); MI_TRY(AS(&x_dec[3], 96 * 128 * T));
+    MI_TRY(AS(&x_dec[4], 48 * 512 * T)); MI_TRY(A(&x_dec[5], (size_t)4 * S * 2048 * T));
+    MI_TRY(AS(&x_tdec[0], (size_t)384 * lp[4])); MI_TRY(AS(&x_tdec[1], (size_t)192 * lp[3])); MI_TRY(AS(&x_tdec[2], (size_t)96 * lp[2]));
+    MI_TRY(AS(&x_tdec[3], (size_t)48 * lp[1])); MI_TRY(A(&x_tdec[4], (size_t)2 * S * lp[0]));
     MI_TRY(A(&x_yt, (size_t)4 * S * 2048 * T)); MI_TRY(A(&x_fr, (size_t)S * T * 2 * 4096));
     const size_t max_rows = B * 512;
     x_stats_bytes = max_rows * kStatSlots * 2 * sizeof(double);
@@ -642,9 +645,10 @@ int HModel::hforward_impl(const float *mix, float *out, int B, int L, hipStream_
             mi_conv_desc r = base_desc(hdec[j].rewrite, k, x_dec[j - 1], C * P, gg);
             r.epi = MI_EPI_GLU; r.y = x_a; r.y_bstride = C * P; r.y_cstride = P;
             const bool tr_tap = tapimg && (!last || last_tap);           // this layer's transposed conv reads an image
+            r.ntaps = 9; r.tap_k2 = 3; r.tap_pad1 = 1; r.tap_pad2 = 1;       // the conv's geometry: the DMA routes need no table
             if (tapimg) {
                 r.xh = j == 2 ? (const void *)x_b : (const void *)x_dec[j - 1]; r.xh_n = (int64_t)B * P;
-                r.wtap = hdec[j].rewrite.wtap; r.ntaps = 9; r.tap_k2 = 3; r.tap_pad1 = 1; r.tap_pad2 = 1;
+                r.wtap = hdec[j].rewrite.wtap;
                 if (tr_tap) { r.flags |= MI_FLAG_IMG; r.yh = x_gimg; r.yh_n = (int64_t)B * P; }
             }
             MI_TRY(conv(r, st));
@@ -666,9 +670,10 @@ int HModel::hforward_impl(const float *mix, float *out, int B, int L, hipStream_
             mi_conv_desc r = base_desc(htdec[j - 1].rewrite, k, x_tdec[j - 2], (int64_t)C * Lq, gg);
             r.epi = MI_EPI_GLU; r.y = x_ta; r.y_bstride = (int64_t)C * Lq; r.y_cstride = Lq;
             const bool tr_tap = tapimg && (!last || last_tap);
+            r.ntaps = 3; r.tap_k2 = 3; r.tap_pad1 = 0; r.tap_pad2 = 1;
             if (tapimg) {
                 r.xh = j == 2 ? (const void *)x_tb : (const void *)x_tdec[j - 2]; r.xh_n = (int64_t)B * Lq;
-                r.wtap = htdec[j - 1].rewrite.wtap; r.ntaps = 3; r.tap_k2 = 3; r.tap_pad1 = 0; r.tap_pad2 = 1;
+                r.wtap = htdec[j - 1].rewrite.wtap;
                 if (tr_tap) { r.flags |= MI_FLAG_IMG; r.yh = x_tgimg; r.yh_n = (int64_t)B * Lq; }
             }
             MI_TRY(conv(r, stt));

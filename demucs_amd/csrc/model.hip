@@ -649,8 +649,12 @@ int Model::fill_workspace(Workspace &w) {
             w.w_eimg[0][i] = pf; w.w_eimg[1][i] = pt;
         }
     // scratch shared by all U-Net layers (largest layer: 48 x 512 x T)
-    MI_TRY(A(&w.w_a, big)); MI_TRY(A(&w.w_b, big)); MI_TRY(A(&w.w_c, big)); MI_TRY(A(&w.w_h, big / 2));
-    MI_TRY(A(&w.w_ta, big)); MI_TRY(A(&w.w_tb, big)); MI_TRY(A(&w.w_tc, big)); MI_TRY(A(&w.w_th, big / 2));
+    MI_TRY(A(&w.w_a, big)); MI_TRY(A(&w.w_b, big)); MI_TRY(A(&w.w_h, big / 2));
+    MI_TRY(A(&w.w_ta, big)); MI_TRY(A(&w.w_tb, big)); MI_TRY(A(&w.w_th, big / 2));
+    // the decoder inputs: the float32 k x k convs read them by LDS-DMA in runs shifted by one sample (gemm_conv.hip
+    // conv_gemm_dmatap_kernel), i.e. up to 4 bytes before the first and 12 after the last element: 128 bytes of slack on both sides
+    MI_TRY(w.alloc((void **)&w.w_c, (big * B + 64) * sizeof(float))); w.w_c += 32;
+    MI_TRY(w.alloc((void **)&w.w_tc, (big * B + 64) * sizeof(float))); w.w_tc += 32;
     // DConv hidden tensors carry round_up(C/8, 16) channels; the padding channels must read as zero
     MI_HIP(hipMemset(w.w_h, 0, (big / 2) * B * sizeof(float)));
     MI_HIP(hipMemset(w.w_th, 0, (big / 2) * B * sizeof(float)));
@@ -1056,7 +1060,8 @@ int Model::run_core_impl(const float *mix, const float *mag, int B, hipStream_t 
             const int64_t P = (int64_t)Fr * T;
             mi_conv_desc r = base_desc(dec[j].rewrite, dec[j].ktab_rw, din, C * P, g);
             r.epi = MI_EPI_GLU; r.y = w_a; r.y_bstride = C * P; r.y_cstride = P;
-            if (tapimg) { r.xh = din; r.xh_n = (int64_t)B * P; r.wtap = dec[j].rewrite.wtap; r.ntaps = 9; r.tap_k2 = 3; r.tap_pad1 = 1; r.tap_pad2 = 1; }
+            r.ntaps = 9; r.tap_k2 = 3; r.tap_pad1 = 1; r.tap_pad2 = 1;       // the conv's geometry: the DMA routes need no table
+            if (tapimg) { r.xh = din; r.xh_n = (int64_t)B * P; r.wtap = dec[j].rewrite.wtap; }
             MI_TRY(conv(r, st));
             MI_TRY(run_dconv(dec[j].dconv, C, g, w_a, w_b, w_h, w_stats, w_st1, w_st2, st));
             const int Cout = last ? 4 * S : kCh[2 - j];
@@ -1081,7 +1086,8 @@ int Model::run_core_impl(const float *mix, const float *mag, int B, hipStream_t 
             const Geo g{B, 1, Lv, 0, L};
             mi_conv_desc r = base_desc(tdec[j].rewrite, tdec[j].ktab_rw, dtin, (int64_t)C * L, g);
             r.epi = MI_EPI_GLU; r.y = w_ta; r.y_bstride = (int64_t)C * L; r.y_cstride = L;
-            if (tapimg) { r.xh = dtin; r.xh_n = (int64_t)B * L; r.wtap = tdec[j].rewrite.wtap; r.ntaps = 3; r.tap_k2 = 3; r.tap_pad1 = 0; r.tap_pad2 = 1; }
+            r.ntaps = 3; r.tap_k2 = 3; r.tap_pad1 = 0; r.tap_pad2 = 1;
+            if (tapimg) { r.xh = dtin; r.xh_n = (int64_t)B * L; r.wtap = tdec[j].rewrite.wtap; }
             MI_TRY(conv(r, stt));
             MI_TRY(run_dconv(tdec[j].dconv, C, g, w_ta, w_tb, w_th, w_stats_t, w_st1_t, w_st2_t, stt, w_gram2_t, gram2t_bytes));
             const int Cout = last ? 2 * S : kCh[2 - j];

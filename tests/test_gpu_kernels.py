@@ -164,6 +164,70 @@ def test_conv_3x3_glu_and_emb(lib, x6):
     assert maxerr(y, want) < 2e-5
 
 
+@pytest.mark.parametrize("Cc,Fr,T,pitch", [(48, 12, 336, 336), (64, 5, 140, 140), (96, 3, 61, 64), (192, 2, 37, 40)])
+def test_float32_3x3_glu_on_the_dma_tap_route(lib, Cc, Fr, T, pitch):
+    """The float32 decoders' 3 x 3 + GLU rewrite conv when its geometry is stated in the descriptor (ntaps / tap_k2 / tap_pad*):
+    the main loop moves shifted runs of the input rows global -> LDS by DMA and writes the conv's zero padding at the row ends in
+    LDS (gemm_conv.hip conv_gemm_dmatap_kernel; 96- and 128-row tiles), instead of walking the gather table.  Against F.conv2d in
+    float64 and, bit for bit, against the table-driven route (same products, same k order); with a row pitch wider than the valid
+    width the padding columns hold NaN: they must never reach a valid output."""
+    B = 2
+    x, W, b = rnd(B, Cc, Fr, T, seed=31), rnd(2 * Cc, Cc, 3, 3, seed=32, scale=0.05), rnd(2 * Cc, seed=33)
+    want = F.glu(F.conv2d(x, W, b, padding=1), dim=1)
+    wt, bias, M, Mpad, K, Kpad, tile = pack_w(W.reshape(2 * Cc, -1), b, glu=True)
+    assert tile in (96, 128)
+    xp = torch.full((B, Cc, Fr, pitch), float("nan"))
+    xp[..., :T] = x.float()
+    P = Fr * pitch
+    # 32 floats of slack on both sides, as the engine's decoder-input buffers carry (the shifted runs start one sample early)
+    buf = torch.full((B * Cc * P + 64,), float("nan"), device="cuda")
+    buf[32:32 + B * Cc * P] = xp.reshape(-1).cuda()
+    xin = buf[32:32 + B * Cc * P]
+    kt = ktab(Cc, 3, 3, 1, 1, 1, 1, P, pitch, Kpad)
+    outs = []
+    for geo in (dict(ntaps=9, tap_k2=3, tap_pad1=1, tap_pad2=1), {}):
+        y = torch.full((B, Cc, Fr, pitch), float("nan"), device="cuda")
+        d = _lib.MiConvDesc()
+        kw = dict(wt=wt, M=M, Mpad=Mpad, K=K, Kpad=Kpad, ktab=kt, x=xin, x_bstride=Cc * P, B=B, D1=Fr, D2=T, O1=Fr, O2=pitch, S1=1, S2=1,
+                  row_mode=1, epi=EPI_GLU, bias=bias, y=y, y_bstride=Cc * P, y_cstride=P, tile_m=tile, o2_valid=T if pitch != T else 0,
+                  x_ld=pitch if pitch != T else 0, **geo)
+        for name, _ in _lib.MiConvDesc._fields_:
+            v = kw.get(name, 0)
+            setattr(d, name, v.data_ptr() if isinstance(v, torch.Tensor) else v)
+        _lib.check(lib.mi_conv_forward(C.byref(d), stream()), "mi_conv_forward")
+        torch.cuda.synchronize()
+        outs.append(y[..., :T].cpu())
+    assert bool(torch.isfinite(outs[0]).all())
+    assert maxerr(outs[0], want) < 2e-5
+    assert torch.equal(outs[0], outs[1])
+
+
+def test_float32_k3_glu_time_branch_on_the_dma_tap_route(lib):
+    """The time-branch rewrite conv (k = 3, padding 1) on rows whose pitch exceeds their valid length (21 499 -> 21 500)."""
+    B, Cc, L, pitch = 2, 96, 21499, 21500
+    x, W, b = rnd(B, Cc, L, seed=34), rnd(2 * Cc, Cc, 3, seed=35, scale=0.05), rnd(2 * Cc, seed=36)
+    want = F.glu(F.conv1d(x, W, b, padding=1), dim=1)
+    wt, bias, M, Mpad, K, Kpad, tile = pack_w(W.reshape(2 * Cc, -1), b, glu=True)
+    buf = torch.full((B * Cc * pitch + 64,), float("nan"), device="cuda")
+    xp = torch.full((B, Cc, pitch), float("nan"))
+    xp[..., :L] = x.float()
+    buf[32:32 + B * Cc * pitch] = xp.reshape(-1).cuda()
+    xin = buf[32:32 + B * Cc * pitch]
+    kt = ktab(Cc, 1, 3, 1, 1, 0, 1, pitch, pitch, Kpad)
+    y = torch.full((B, Cc, pitch), float("nan"), device="cuda")
+    d = _lib.MiConvDesc()
+    kw = dict(wt=wt, M=M, Mpad=Mpad, K=K, Kpad=Kpad, ktab=kt, x=xin, x_bstride=Cc * pitch, B=B, D1=1, D2=L, O1=1, O2=pitch, S1=1, S2=1,
+              epi=EPI_GLU, bias=bias, y=y, y_bstride=Cc * pitch, y_cstride=pitch, tile_m=tile, o2_valid=L, x_ld=pitch, ntaps=3, tap_k2=3,
+              tap_pad1=0, tap_pad2=1)
+    for name, _ in _lib.MiConvDesc._fields_:
+        v = kw.get(name, 0)
+        setattr(d, name, v.data_ptr() if isinstance(v, torch.Tensor) else v)
+    _lib.check(lib.mi_conv_forward(C.byref(d), stream()), "mi_conv_forward")
+    torch.cuda.synchronize()
+    got = y[..., :L].cpu()
+    assert bool(torch.isfinite(got).all()) and maxerr(got, want) < 2e-5
+
+
 def test_linear_scale_residual_big_k(lib, x6):
     """nn.Linear on channel-first tokens with LayerScale + residual epilogue (transformer.py:364-367):
     M=512, K=2048 exercises the 128-row tile and a long contraction."""
