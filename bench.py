@@ -285,9 +285,9 @@ def main():
                           "achieved": round(t_ach, 2), "frac": round(t_ach / peak, 4),
                           "sum_of_class_ms_per_step": round(sum(r["ms"] for r in rows_timed) / args.steps, 2),
                           "note": "event-bracketed durations overlap across the two streams (their per-step sum exceeds ms_per_step): "
-                                  "agrees with profiles/round3_f32_kernel_stats.csv (the default command)"}
+                                  "agrees with profiles/round4_f32_kernel_stats.csv (the default command)"}
         traffic, traffic_src = None, None        # HBM bytes per launch from the committed PMC passes of this same command
-        for tname in ("round3_traffic.json", "round2_traffic.json", "round1_traffic.json"):
+        for tname in ("round4_traffic.json", "round3_traffic.json", "round2_traffic.json", "round1_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", tname)
             if traffic is None and os.path.exists(tpath) and world == 1 and args.batch == 32 and seconds == TRACK_SECONDS:
                 entry = json.load(open(tpath)).get(dom["name"] + ("" if args.dtype == "f32" else "@" + args.dtype))
@@ -317,7 +317,7 @@ def main():
                          "unit": unit, "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "measured": (f"HIP events on the launch stream over {iso_steps} passes of the same workload run right after the timed "
                                       "region with ONE kernel on the GPU at a time (mi_set_two_streams(0)); agrees with "
-                                      "profiles/round3_f32_one_stream_kernel_stats.csv") if iso_steps else
+                                      "profiles/round4_f32_one_stream_kernel_stats.csv") if iso_steps else
                                      "HIP events on the launch streams over the timed region itself (--no-iso-pass: durations of the two streams overlap)",
                          "in_timed_region": timed_roof,
                          "pipe": ("bf16 MFMA, 6 products per fp32 MAC (exact 3-term operand split, fp32 accumulate)" if x6

@@ -31,6 +31,9 @@ def klass(name):
     m = re.search(r"conv_gemm_dma_kernel<(\d+), (\d+)>", name)      # LDS-DMA main loop of the plain 128-row LINEAR tile
     if m:
         return f"conv_gemm<{EPI[int(m.group(1))]},tile128,1x1>"
+    m = re.search(r"conv_gemm_dmatap_kernel<(\d+), (\d+), (\d+)>", name)      # round 4: LDS-DMA main loop of the float32 k x k GLU convs
+    if m:
+        return f"conv_gemm<{EPI[int(m.group(2))]},tile{m.group(1)}>"
     m = re.search(r"conv_gemm_x6_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (true|false)>", name)
     if m:
         wm, wn, tm, tn, epi, _, plain = m.groups()
@@ -45,11 +48,14 @@ def klass(name):
         return f"conv_gemm_{'bf16' if m.group(1) == '1' else 'f16'}<linear,tile128,1x1>"
     # kernels named in north_star's HBM-bound list: STFT (K1), iSTFT (K15), the fused DConv kernels, the scheduler's OLA
     for k in ("attention_heads_kernel", "attention_half_kernel", "attention_kernel", "dconv_rowlds_kernel", "dconv_row_kernel", "dconv_t_conv3_kernel", "dconv_t_gram_kernel", "dconv_t_out_kernel",
-              "istft_frames_kernel", "istft_ola_kernel", "stft_frames_kernel", "cac_transpose_kernel", "spec_transpose_kernel",
+              "istft_fused_kernel", "istft_frames_kernel", "istft_ola_kernel", "lstm_persist_kernel", "stft_frames_kernel", "cac_transpose_kernel", "spec_transpose_kernel",
               "ola_accumulate_kernel", "ola_finish_kernel", "segments_gather_kernel", "token_tile_kernel", "row_stats_kernel", "gn_gelu_kernel"):
         if k in name:
             return k
     return None
+
+
+DMA_TAP = set()        # classes seen running conv_gemm_dmatap_kernel
 
 
 def collect(d, counter):
@@ -59,6 +65,8 @@ def collect(d, counter):
             if r["Counter_Name"] != counter:
                 continue
             k = klass(r["Kernel_Name"])
+            if k and "conv_gemm_dmatap_kernel" in r["Kernel_Name"]:
+                DMA_TAP.add(k)
             if k:
                 out[k][0] += 1
                 out[k][1] += float(r["Counter_Value"])
@@ -74,7 +82,8 @@ def main():
         wn, ws = w.get(k, [0, 0.0])
         rd = 2.0 * fs * 1024 / n
         wr = ws * 1024 / max(1, wn)
-        gather = k.startswith("conv_gemm") and not k.endswith(",1x1>")      # table-driven dword gathers: the x2 factor is uncalibrated
+        # table-driven dword gathers: the x2 factor is uncalibrated (the float32 k x k GLU convs left that class in round 4: 16-byte DMA runs)
+        gather = k.startswith("conv_gemm") and not k.endswith(",1x1>") and k not in DMA_TAP
         res[k] = {"launches_sampled": n, "read_bytes_per_launch": round(rd), "write_bytes_per_launch": round(wr),
                   "traffic_bytes_per_launch": round(rd + wr), "read_access": "dword gather" if gather else "wide (>= 8 B per lane)",
                   "read_bytes_x1": round(rd / 2),

@@ -2,7 +2,7 @@
 # tests: full GPU suite + the default bench line; profiles: rocprofv3 kernel stats of the bench command (fp32, bf16), of the
 # hdemucs_mmi fp16 pass, and the two PMC passes for HBM traffic.
 set -o pipefail
-R=$GRAFT_REPO_ROOT; tag=${1:-round3}; stage=${2:-all}; O=$R/gpurun_out/$tag; mkdir -p $O
+R=$GRAFT_REPO_ROOT; tag=${1:-round4}; stage=${2:-all}; O=$R/gpurun_out/$tag; mkdir -p $O
 if [ $stage != profiles ]; then
 timeout -k 10 1000 python -m pytest tests -m gpu -q -s > $O/tests.log 2>&1; echo "tests rc $?" >> $O/tests.log; tail -3 $O/tests.log
 timeout -k 10 400 python bench.py --steps 10 --warmup 2 > $O/bench.json 2> $O/bench.err; tail -c 600 $O/bench.json
