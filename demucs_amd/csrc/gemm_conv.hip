@@ -418,6 +418,15 @@ static int launch_cfg(const mi_conv_desc &d, hipStream_t st) {
 
 template <int EPI, int LFLAGS, bool PLAIN>
 static int launch_tile(const mi_conv_desc &d, int tile, hipStream_t st) {
+    if constexpr (PLAIN && EPI == MI_EPI_LINEAR) {
+        // Small batches: a plain linear layer whose 128-row tiles give fewer workgroups than the chip has CUs (B = 1: M = 512 and
+        // 2 688 tokens -> 84) runs on 64-row tiles instead -- twice the workgroups at a lower per-workgroup rate.  MI_SMALL_TILE=0: off
+        static const int small = getenv("MI_SMALL_TILE") ? atoi(getenv("MI_SMALL_TILE")) : 1;
+        if (small && tile == 128 && d.Mpad % 64 == 0) {
+            const int64_t wgs = (int64_t)(d.Mpad / 128) * ceil_div((int64_t)d.B * d.O1 * d.O2, BN);
+            if (wgs < 200) tile = 64;
+        }
+    }
     switch (tile) {
         case 128: return launch_cfg<2, 2, 2, 2, EPI, LFLAGS, PLAIN>(d, st);
         case 96: return launch_cfg<1, 4, 3, 1, EPI, LFLAGS, PLAIN>(d, st);
