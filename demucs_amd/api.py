@@ -38,12 +38,17 @@ def _with(d: Optional[dict], **subs) -> dict:
 
 
 class Separator:
-    def __init__(self, model, device="cuda", shifts: int = 1, overlap: float = 0.25, split: bool = True,
+    def __init__(self, model, repo=None, device="cuda", shifts: int = 1, overlap: float = 0.25, split: bool = True,
                  segment: Optional[int] = None, jobs: int = 0, progress: bool = False,
                  callback: Optional[Callable[[dict], None]] = None, callback_arg: Optional[dict] = None):
         if isinstance(model, str):
-            raise LoadModelError(f"model zoo entry {model!r} cannot be fetched offline: pass a demucs_amd.HTDemucs or "
-                                 "BagOfModels built from a locally loaded state dict")
+            # api.py:99-104: `Separator(model=name, repo=folder)`; offline only "demucs_unittest" and local folders resolve
+            from .pretrained import get_model
+            from .states import ModelLoadingError
+            try:
+                model = get_model(model, repo)
+            except ModelLoadingError as exc:
+                raise LoadModelError(str(exc)) from exc
         self._model = model
         self._audio_channels = model.audio_channels
         self._samplerate = model.samplerate

@@ -194,6 +194,42 @@ void pack_lstm_whh(const float *whh, int H, float *packed) {
                     }
 }
 
+// ---- any other (small) hidden size: the reference's own `demucs_unittest` model is HDemucs(channels=4) (pretrained.py:27-29), whose
+// layers 4 / 5 have H = 16 / 32.  One workgroup per (sequence, direction) walks the W steps with W_hh (natural (2, 4H, H) order) and
+// h in LDS; thread j < 4H owns gate row j.  Plain fmaf chains in k order: not a performance path.
+__global__ __launch_bounds__(256) void lstm_small_kernel(const float *__restrict__ gx, const float *__restrict__ whh, float *__restrict__ out, int N, int H,
+                                                         int W) {
+    extern __shared__ float lsm[];
+    float *wl = lsm, *hs = wl + 4 * H * H, *gs = hs + H;
+    const int n = blockIdx.x, dir = blockIdx.y, j = threadIdx.x;
+    for (int i = j; i < 4 * H * H; i += 256) wl[i] = whh[(size_t)dir * 4 * H * H + i];
+    if (j < H) hs[j] = 0.f;
+    float c = 0.f;
+    __syncthreads();
+    for (int s = 0; s < W; ++s) {
+        const int t = dir ? W - 1 - s : s;
+        if (j < 4 * H) {
+            float a = 0.f;
+            for (int k = 0; k < H; ++k) a = fmaf(wl[j * H + k], hs[k], a);
+            gs[j] = gx[(((size_t)n * 2 + dir) * 4 * H + j) * W + t] + a;
+        }
+        __syncthreads();
+        if (j < H) {
+            const float h = lstm_cell(gs[j], gs[H + j], gs[2 * H + j], gs[3 * H + j], c, lstm_tag(s));
+            hs[j] = h;
+            out[((size_t)n * 2 * H + dir * H + j) * W + t] = h;
+        }
+        __syncthreads();
+    }
+}
+
+int launch_lstm_small(const float *gx, const float *whh_natural, int N, int H, int W, float *out, hipStream_t st) {
+    MI_REQUIRE(H >= 1 && H <= 64, "lstm: hidden size %d has no kernel (192 / 384: matrix-pipe kernels; <= 64: the generic one)", H);
+    hipLaunchKernelGGL(lstm_small_kernel, dim3(N, 2), dim3(256), (size_t)(4 * H * H + 5 * H) * sizeof(float), st, gx, whh_natural, out, N, H, W);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+
 // state: 3 buffers of 2 x N x H floats (h ping, h pong, c), zeroed here
 int launch_lstm_seq(const float *gx, const float *whh, int N, int H, int W, float *out, float *state, hipStream_t st) {
     MI_REQUIRE(H == 192 || H == 384, "lstm: hidden size %d not instantiated", H);
@@ -354,8 +390,43 @@ __global__ __launch_bounds__(128) void local_attn_kernel(const float *__restrict
     }
 }
 
+// LocalState for any other width (head dimension C / 4 <= 16: demucs_unittest's 4 / 8): one thread per (item, head, query) with an
+// online softmax over all keys, same definition as above
+__global__ __launch_bounds__(256) void local_attn_small_kernel(const float *__restrict__ qkc, int C, int T, int ld, float *__restrict__ out, int ld_o) {
+    const int s = blockIdx.x * 256 + threadIdx.x, head = blockIdx.y, b = blockIdx.z, dh = C / 4;
+    if (s >= T) return;
+    const float *base = qkc + (size_t)b * (3 * C + 16) * ld;
+    const float *qp = base + (size_t)head * dh * ld, *kp = base + (size_t)(C + head * dh) * ld, *vp = base + (size_t)(2 * C + head * dh) * ld,
+                *dp = base + (size_t)(3 * C + head * 4) * ld;
+    const float isq = 1.0f / sqrtf((float)dh);
+    float q[16], o[16];
+    for (int d = 0; d < dh; ++d) { q[d] = qp[(size_t)d * ld + s] * isq; o[d] = 0.f; }
+    float slope = 0.f;
+    for (int f = 0; f < 4; ++f) slope += (float)(f + 1) * (sigmoid_f(dp[(size_t)f * ld + s]) * 0.5f);
+    slope *= 0.5f;
+    float mrun = -INFINITY, lrun = 0.f;
+    for (int t = 0; t < T; ++t) {
+        float sc = 0.f;
+        for (int d = 0; d < dh; ++d) sc = fmaf(kp[(size_t)d * ld + t], q[d], sc);
+        sc -= fabsf((float)(t - s)) * slope;
+        if (t == s) sc = -100.f;
+        const float mnew = fmaxf(mrun, sc), alpha = __expf(mrun - mnew), p = __expf(sc - mnew);
+        lrun = lrun * alpha + p;
+        for (int d = 0; d < dh; ++d) o[d] = o[d] * alpha + p * vp[(size_t)d * ld + t];
+        mrun = mnew;
+    }
+    const float inv = 1.0f / lrun;
+    for (int d = 0; d < dh; ++d) out[((size_t)b * C + head * dh + d) * ld_o + s] = o[d] * inv;
+}
+
 int launch_local_attn(const float *qkc, int B, int C, int T, int ld, float *out, int ld_o, hipStream_t st) {
     MI_REQUIRE(ld % 4 == 0 && ld >= T && ((uintptr_t)qkc & 15) == 0, "local_attn: row pitch %d must be a multiple of 4 (T = %d)", ld, T);
+    if (C != 192 && C != 384) {
+        MI_REQUIRE(C % 4 == 0 && C / 4 <= 16, "local_attn: %d channels not instantiated", C);
+        hipLaunchKernelGGL(local_attn_small_kernel, dim3(ceil_div(T, 256), 4, B), dim3(256), 0, st, qkc, C, T, ld, out, ld_o);
+        MI_CHECK_LAUNCH();
+        return MI_OK;
+    }
     const dim3 grid(ceil_div(T, 64), 4, B);
     if (C == 192) hipLaunchKernelGGL(local_attn_kernel<48>, grid, dim3(128), 0, st, qkc, C, T, ld, out, ld_o);
     else if (C == 384) hipLaunchKernelGGL(local_attn_kernel<96>, grid, dim3(128), 0, st, qkc, C, T, ld, out, ld_o);

@@ -35,6 +35,7 @@ struct HGeo {                   // everything that depends on the input length
 
 struct HModel : Model {
     int Lmax = 0, Tmax = 0;
+    int hCh[7] = {};             // layer widths: channels << level (48 ... 3 072 for hdemucs_mmi; 4 ... 256 for demucs_unittest)
     HEncW henc[6], htenc[5];
     HDecW hdec[6], htdec[5];
     std::map<int, HGeo> geos;              // at most kMaxGeos cached input lengths (LRU): every track's tail chunk and every

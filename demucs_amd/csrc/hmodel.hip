@@ -20,7 +20,6 @@ constexpr int kMinLength = 1;          // the reference forwards chunks down to 
                                        // branch rows carry a pitch >= 32 frames (the row-statistics epilogues reduce 32 columns at a time)
 constexpr size_t kMaxGeos = 24;        // cached input lengths per handle (least recently used one evicted)
 static const int hFr[5] = {2048, 512, 128, 32, 8};
-static const int hCh[4] = {48, 96, 192, 384};
 
 int HModel::halloc(void **p, size_t bytes) {
     bytes = (bytes + 255) & ~(size_t)255;
@@ -72,9 +71,11 @@ int HModel::load_deep(const WeightTable &wt, const std::string &prefix, int C, H
             }
         }
         MI_TRY(pack_conv(wih.data(), bih.data(), 8 * H, Kin, false, &l->ih[layer]));
-        std::vector<float> packed(whh.size());
-        pack_lstm_whh(whh.data(), H, packed.data());
-        MI_TRY(upload(packed, &l->whhT[layer]));
+        if (H == 192 || H == 384) {          // the matrix-pipe kernels' operand order
+            std::vector<float> packed(whh.size());
+            pack_lstm_whh(whh.data(), H, packed.data());
+            MI_TRY(upload(packed, &l->whhT[layer]));
+        } else MI_TRY(upload(whh, &l->whhT[layer]));     // small widths (demucs_unittest): natural order for lstm_small_kernel
     }
     MI_TRY(wt.get(p + ".3.linear.weight", (int64_t)H * 2 * H, &w)); MI_TRY(wt.get(p + ".3.linear.bias", H, &b));
     MI_TRY(pack_conv(w, b, H, 2 * H, false, &l->lin));
@@ -111,6 +112,16 @@ int HModel::hinit(const mi_config &c, const mi_tensor_desc *weights, size_t n) {
     S = c.n_sources; Lmax = c.segment_length; Tmax = (Lmax + 1023) / 1024;
     WeightTable wt;
     for (size_t i = 0; i < n; ++i) wt.t[weights[i].name] = {weights[i].data, weights[i].numel};
+    {   // layer widths: `channels` of the reference constructor (hdemucs.py:366) = rows of encoder.0's bias; 48 for hdemucs_mmi, 4 for
+        // the reference's own `demucs_unittest` model (pretrained.py:27-29); growth 2 per layer
+        auto it = wt.t.find("encoder.0.conv.bias");
+        MI_REQUIRE(it != wt.t.end(), "missing tensor 'encoder.0.conv.bias'");
+        const int64_t c0 = it->second.second;
+        MI_REQUIRE(c0 == 48 || c0 == 4, "HDemucs channels = %lld: the engine runs 48 (hdemucs_mmi) and 4 (demucs_unittest); other widths have "
+                   "neither the matrix-pipe nor the generic recurrence / attention kernels", (long long)c0);
+        for (int i = 0; i < 7; ++i) hCh[i] = (int)c0 << i;
+    }
+    const int C0 = hCh[0], C3 = hCh[3], C4 = hCh[4], C5 = hCh[5], C6 = hCh[6];
     {   // FFT tables (as in Model::init)
         std::vector<float> win(4096), env(1024);
         std::vector<float2> tw(2048);
@@ -140,18 +151,18 @@ int HModel::hinit(const mi_config &c, const mi_tensor_desc *weights, size_t n) {
     }
     {   // frequency embedding 0.2 * (10 * weight).t() -> [48][512]
         const float *ew;
-        MI_TRY(wt.get("freq_emb.embedding.weight", 512 * 48, &ew));
-        std::vector<float> emb(48 * 512);
+        MI_TRY(wt.get("freq_emb.embedding.weight", (int64_t)512 * C0, &ew));
+        std::vector<float> emb((size_t)C0 * 512);
         for (int f = 0; f < 512; ++f)
-            for (int ch = 0; ch < 48; ++ch) emb[ch * 512 + f] = 0.2f * (ew[f * 48 + ch] * 10.0f);
+            for (int c = 0; c < C0; ++c) emb[(size_t)c * 512 + f] = 0.2f * (ew[(size_t)f * C0 + c] * 10.0f);
         MI_TRY(upload(emb, &freq_emb));
     }
     // tencoder.4: the "empty" layer (conv only) whose output is injected into encoder.4
-    MI_TRY(wt.get("tencoder.4.conv.weight", (int64_t)768 * 384 * 8, &w)); MI_TRY(wt.get("tencoder.4.conv.bias", 768, &b));
-    MI_TRY(pack_conv(w, b, 768, 384 * 8, false, &htenc[4].conv));
+    MI_TRY(wt.get("tencoder.4.conv.weight", (int64_t)C4 * C3 * 8, &w)); MI_TRY(wt.get("tencoder.4.conv.bias", C4, &b));
+    MI_TRY(pack_conv(w, b, C4, C3 * 8, false, &htenc[4].conv));
     // encoder.4 (last frequency layer, Fr 8 -> 1) and encoder.5 (time layer k = 4, s = 2): GroupNorm(4), deep DConv
     for (int i = 4; i < 6; ++i) {
-        const int Cin = i == 4 ? 384 : 768, C = 2 * Cin, ker = i == 4 ? 8 : 4;
+        const int Cin = i == 4 ? C3 : C4, C = 2 * Cin, ker = i == 4 ? 8 : 4;
         const std::string p = "encoder." + std::to_string(i);
         MI_TRY(wt.get(p + ".conv.weight", (int64_t)C * Cin * ker, &w)); MI_TRY(wt.get(p + ".conv.bias", C, &b));
         MI_TRY(pack_conv(w, b, C, Cin * ker, false, &henc[i].conv));
@@ -162,25 +173,25 @@ int HModel::hinit(const mi_config &c, const mi_tensor_desc *weights, size_t n) {
         for (int d = 0; d < 2; ++d) MI_TRY(load_deep(wt, p, C, &henc[i].deep[d], d));
     }
     // decoder.0 (mirror of encoder.5): Conv1d k3 -> GN -> GLU -> ConvTranspose1d(k4, s2) -> GN -> crop -> GELU
-    MI_TRY(wt.get("decoder.0.rewrite.weight", (int64_t)3072 * 1536 * 3, &rw)); MI_TRY(wt.get("decoder.0.rewrite.bias", 3072, &rb));
-    MI_TRY(pack_conv(rw, rb, 3072, 1536 * 3, false, &hdec[0].rewrite));
-    MI_TRY(load_norm(wt, "decoder.0.norm1", 3072, &hdec[0].n1w, &hdec[0].n1b));
-    MI_TRY(wt.get("decoder.0.conv_tr.weight", (int64_t)1536 * 768 * 4, &w)); MI_TRY(wt.get("decoder.0.conv_tr.bias", 768, &b));
-    MI_TRY(pack_convtr(w, b, 1536, 768, &hdec[0].convtr, 2));
-    MI_TRY(load_norm(wt, "decoder.0.norm2", 768, &hdec[0].n2w, &hdec[0].n2b));
+    MI_TRY(wt.get("decoder.0.rewrite.weight", (int64_t)C6 * C5 * 3, &rw)); MI_TRY(wt.get("decoder.0.rewrite.bias", C6, &rb));
+    MI_TRY(pack_conv(rw, rb, C6, C5 * 3, false, &hdec[0].rewrite));
+    MI_TRY(load_norm(wt, "decoder.0.norm1", C6, &hdec[0].n1w, &hdec[0].n1b));
+    MI_TRY(wt.get("decoder.0.conv_tr.weight", (int64_t)C5 * C4 * 4, &w)); MI_TRY(wt.get("decoder.0.conv_tr.bias", C4, &b));
+    MI_TRY(pack_convtr(w, b, C5, C4, &hdec[0].convtr, 2));
+    MI_TRY(load_norm(wt, "decoder.0.norm2", C4, &hdec[0].n2w, &hdec[0].n2b));
     {   // decoder.1 (mirror of encoder.4, Fr = 1): of the 3x3 rewrite only the middle frequency row ever meets data
-        MI_TRY(wt.get("decoder.1.rewrite.weight", (int64_t)1536 * 768 * 9, &rw)); MI_TRY(wt.get("decoder.1.rewrite.bias", 1536, &rb));
-        std::vector<float> mid((size_t)1536 * 768 * 3);
-        for (size_t mc = 0; mc < (size_t)1536 * 768; ++mc)
+        MI_TRY(wt.get("decoder.1.rewrite.weight", (int64_t)C5 * C4 * 9, &rw)); MI_TRY(wt.get("decoder.1.rewrite.bias", C5, &rb));
+        std::vector<float> mid((size_t)C5 * C4 * 3);
+        for (size_t mc = 0; mc < (size_t)C5 * C4; ++mc)
             for (int k2 = 0; k2 < 3; ++k2) mid[mc * 3 + k2] = rw[mc * 9 + 3 + k2];
-        MI_TRY(pack_conv(mid.data(), rb, 1536, 768 * 3, false, &hdec[1].rewrite));
-        MI_TRY(load_norm(wt, "decoder.1.norm1", 1536, &hdec[1].n1w, &hdec[1].n1b));
-        MI_TRY(wt.get("decoder.1.conv_tr.weight", (int64_t)768 * 384 * 8, &w)); MI_TRY(wt.get("decoder.1.conv_tr.bias", 384, &b));
-        MI_TRY(pack_convtr(w, b, 768, 384, &hdec[1].convtr, 4));
-        MI_TRY(load_norm(wt, "decoder.1.norm2", 384, &hdec[1].n2w, &hdec[1].n2b));
-        MI_TRY(wt.get("tdecoder.0.conv_tr.weight", (int64_t)768 * 384 * 8, &w)); MI_TRY(wt.get("tdecoder.0.conv_tr.bias", 384, &b));
-        MI_TRY(pack_convtr(w, b, 768, 384, &htdec[0].convtr, 4));
-        MI_TRY(load_norm(wt, "tdecoder.0.norm2", 384, &htdec[0].n2w, &htdec[0].n2b));
+        MI_TRY(pack_conv(mid.data(), rb, C5, C4 * 3, false, &hdec[1].rewrite));
+        MI_TRY(load_norm(wt, "decoder.1.norm1", C5, &hdec[1].n1w, &hdec[1].n1b));
+        MI_TRY(wt.get("decoder.1.conv_tr.weight", (int64_t)C4 * C3 * 8, &w)); MI_TRY(wt.get("decoder.1.conv_tr.bias", C3, &b));
+        MI_TRY(pack_convtr(w, b, C4, C3, &hdec[1].convtr, 4));
+        MI_TRY(load_norm(wt, "decoder.1.norm2", C3, &hdec[1].n2w, &hdec[1].n2b));
+        MI_TRY(wt.get("tdecoder.0.conv_tr.weight", (int64_t)C4 * C3 * 8, &w)); MI_TRY(wt.get("tdecoder.0.conv_tr.bias", C3, &b));
+        MI_TRY(pack_convtr(w, b, C4, C3, &htdec[0].convtr, 4));
+        MI_TRY(load_norm(wt, "tdecoder.0.norm2", C3, &htdec[0].n2w, &htdec[0].n2b));
     }
     for (int j = 2; j < 6; ++j) {                         // decoder.2-5 / tdecoder.1-4: htdemucs-shaped, no DConv (dconv_mode = 1)
         const int i = 5 - j, C = hCh[i];
@@ -204,14 +215,17 @@ int HModel::hinit(const mi_config &c, const mi_tensor_desc *weights, size_t n) {
     for (int i = 0; i < 6; ++i) lp[i] = round_up(lt[i], 4);
     auto A = [&](float **p, size_t per_item) { return halloc((void **)p, (per_item + 64) * B * sizeof(float)); };
     MI_TRY(A(&x_t0, (size_t)2 * lp[0])); MI_TRY(A(&x_zt, 4 * 2048 * T)); MI_TRY(A(&x_0, 4 * 2048 * T));
-    size_t big = 0;
+    size_t big = 0, hid = 0;          // largest layer tensor; largest DConv hidden tensor (round_up(C / 4, 16) channels: more than C when C < 16)
     for (int i = 0; i < 4; ++i) {
         const size_t nf = (size_t)hCh[i] * hFr[i + 1] * T, nt = (size_t)hCh[i] * lp[i + 1];
         MI_TRY(A(&x_skip[i], nf)); MI_TRY(A(&x_skip_t[i], nt));
         big = std::max(big, std::max(nf, nt));
+        const size_t hpad = round_up(hCh[i] / 4, 16);
+        hid = std::max(hid, std::max(hpad * hFr[i + 1] * T, hpad * (size_t)lp[i + 1]));
     }
-    MI_TRY(A(&x_skip[4], 768 * T)); MI_TRY(A(&x_skip[5], 1536 * T5)); MI_TRY(A(&x_inject, 768 * T));
-    MI_TRY(A(&x_a, big)); MI_TRY(A(&x_b, big)); MI_TRY(A(&x_h, big / 2)); MI_TRY(A(&x_ta, big)); MI_TRY(A(&x_tb, big)); MI_TRY(A(&x_th, big / 2));
+    hid = std::max(hid, big / 2);
+    MI_TRY(A(&x_skip[4], C4 * T)); MI_TRY(A(&x_skip[5], C5 * T5)); MI_TRY(A(&x_inject, C4 * T));
+    MI_TRY(A(&x_a, big)); MI_TRY(A(&x_b, big)); MI_TRY(A(&x_h, hid)); MI_TRY(A(&x_ta, big)); MI_TRY(A(&x_tb, big)); MI_TRY(A(&x_th, hid));
     if (c.dtype != MI_DTYPE_F32) {
         MI_TRY(A(&x_gimg, big / 2)); MI_TRY(A(&x_tgimg, big / 2));         // half modes: operand images of the decoders' GLU outputs
         for (int i = 0; i < 3; ++i) {            // ... and phase-split images of the encoder outputs 0..2 (gemm_conv.h MI_FLAG_IMG4)
@@ -220,26 +234,26 @@ int HModel::hinit(const mi_config &c, const mi_tensor_desc *weights, size_t n) {
             MI_TRY(A(&x_eimg[0][i], 2 * hCh[i] * pqf)); MI_TRY(A(&x_eimg[1][i], 2 * hCh[i] * pqt));
         }
     }
-    MI_HIP(hipMemset(x_h, 0, (big / 2 + 64) * B * sizeof(float)));        // hidden tensors carry zero padding channels
-    MI_HIP(hipMemset(x_th, 0, (big / 2 + 64) * B * sizeof(float)));
-    const size_t zsz = std::max<size_t>(3072 * (T5 + 2), std::max<size_t>(3072 * T + 64, 384 * (4 * T + 8)));   // largest: decoder.1's 384 x 8 x T
+    MI_HIP(hipMemset(x_h, 0, (hid + 64) * B * sizeof(float)));        // hidden tensors carry zero padding channels
+    MI_HIP(hipMemset(x_th, 0, (hid + 64) * B * sizeof(float)));
+    const size_t zsz = std::max<size_t>(C6 * (T5 + 2), std::max<size_t>(C6 * T + 64, C3 * (4 * T + 8)));   // largest: decoder.1's 384 x 8 x T
     MI_TRY(A(&x_zA, zsz)); MI_TRY(A(&x_zB, zsz));
-    MI_TRY(A(&x_a4, 1536 * (T5 + 2))); MI_TRY(A(&x_b4, 1536 * (T5 + 2))); MI_TRY(A(&x_pre, 1536 * (T5 + 2)));
+    MI_TRY(A(&x_a4, C5 * (T5 + 2))); MI_TRY(A(&x_b4, C5 * (T5 + 2))); MI_TRY(A(&x_pre, C5 * (T5 + 2)));
     const size_t fw = 2 * T + 600;                      // frames x 200 steps of the BLSTM chunking
-    MI_TRY(A(&x_dh, 384 * T)); MI_TRY(A(&x_dy1, 384 * T)); MI_TRY(A(&x_dy2, 384 * T)); MI_TRY(A(&x_dy3, 384 * T));
-    MI_TRY(A(&x_xf, 384 * fw)); MI_TRY(A(&x_gx, 3072 * fw)); MI_TRY(A(&x_o0, 768 * fw)); MI_TRY(A(&x_o1, 768 * fw)); MI_TRY(A(&x_xl, 384 * fw));
-    MI_TRY(A(&x_qkc, (3 * 384 + 16) * T)); MI_TRY(A(&x_att, 384 * T));
-    MI_TRY(A(&x_lstm, 6 * 384 * (fw / 200 + 2)));          // LSTM state: h ping / pong and c for every (direction, sequence)
+    MI_TRY(A(&x_dh, C3 * T)); MI_TRY(A(&x_dy1, C3 * T)); MI_TRY(A(&x_dy2, C3 * T)); MI_TRY(A(&x_dy3, C3 * T));
+    MI_TRY(A(&x_xf, C3 * fw)); MI_TRY(A(&x_gx, C6 * fw)); MI_TRY(A(&x_o0, C4 * fw)); MI_TRY(A(&x_o1, C4 * fw)); MI_TRY(A(&x_xl, C3 * fw));
+    MI_TRY(A(&x_qkc, (3 * C3 + 16) * T)); MI_TRY(A(&x_att, C3 * T));
+    MI_TRY(A(&x_lstm, 6 * C3 * (fw / 200 + 2)));          // LSTM state: h ping / pong and c for every (direction, sequence)
     MI_TRY(halloc(&x_lstm_scratch, lstm_persist_scratch_bytes()));
     MI_HIP(hipHostMalloc((void **)&lstm_timeout, 64, hipHostMallocMapped));
     *lstm_timeout = 0;
     // (the decoder inputs carry 128 bytes of slack in front as well: the float32 k x k convs read them by LDS-DMA in runs shifted
     // by one sample, gemm_conv.hip conv_gemm_dmatap_kernel; A() already leaves 64 floats per item behind)
     auto AS = [&](float **p, size_t per_item) { const int r = halloc((void **)p, ((per_item + 64) * B + 64) * sizeof(float)); if (r == MI_OK) *p += 32; return r; };
-    MI_TRY(A(&x_dec[0], 768 * T)); MI_TRY(AS(&x_dec[1], 384 * 8 * T)); MI_TRY(AS(&x_dec[2], 192 * 32 * T)); MI_TRY(AS(&x_dec[3], 96 * 128 * T));
-    MI_TRY(AS(&x_dec[4], 48 * 512 * T)); MI_TRY(A(&x_dec[5], (size_t)4 * S * 2048 * T));
-    MI_TRY(AS(&x_tdec[0], (size_t)384 * lp[4])); MI_TRY(AS(&x_tdec[1], (size_t)192 * lp[3])); MI_TRY(AS(&x_tdec[2], (size_t)96 * lp[2]));
-    MI_TRY(AS(&x_tdec[3], (size_t)48 * lp[1])); MI_TRY(A(&x_tdec[4], (size_t)2 * S * lp[0]));
+    MI_TRY(A(&x_dec[0], C4 * T)); MI_TRY(AS(&x_dec[1], C3 * 8 * T)); MI_TRY(AS(&x_dec[2], hCh[2] * 32 * T)); MI_TRY(AS(&x_dec[3], hCh[1] * 128 * T));
+    MI_TRY(AS(&x_dec[4], hCh[0] * 512 * T)); MI_TRY(A(&x_dec[5], (size_t)4 * S * 2048 * T));
+    MI_TRY(AS(&x_tdec[0], (size_t)C3 * lp[4])); MI_TRY(AS(&x_tdec[1], (size_t)hCh[2] * lp[3])); MI_TRY(AS(&x_tdec[2], (size_t)hCh[1] * lp[2]));
+    MI_TRY(AS(&x_tdec[3], (size_t)hCh[0] * lp[1])); MI_TRY(A(&x_tdec[4], (size_t)2 * S * lp[0]));
     MI_TRY(A(&x_yt, (size_t)4 * S * 2048 * T)); MI_TRY(A(&x_fr, (size_t)S * T * 2 * 4096));
     const size_t max_rows = B * 512;
     x_stats_bytes = max_rows * kStatSlots * 2 * sizeof(double);
@@ -343,6 +357,7 @@ int HModel::group_norm(const float *x, int B, int C, int G, int in_pitch, int in
 }
 
 int HModel::run_lstm(const float *gx, const float *whh, int N, int H, int W, float *out, hipStream_t st) {
+    if (H != 192 && H != 384) return launch_lstm_small(gx, whh, N, H, W, out, st);
     if (lstm_step_chain()) return launch_lstm_seq(gx, whh, N, H, W, out, x_lstm, st);
     return launch_lstm_persist(gx, whh, N, H, W, out, x_lstm_scratch, lstm_timeout, st);
 }
@@ -443,6 +458,7 @@ int HModel::hforward_impl(const float *mix, float *out, int B, int L, hipStream_
     HGeo *gp;
     MI_TRY(geometry(L, &gp));
     HGeo &g = *gp;
+    const int C3 = hCh[3], C4 = hCh[4], C5 = hCh[5], C6 = hCh[6];        // layer widths: channels << level
     const int T = g.T, T5 = g.T5, Tp = g.Tp;
     const int *Lt = g.Lt, *Lp = g.Lp;
     const mi_ktab_entry *k;
@@ -480,7 +496,8 @@ int HModel::hforward_impl(const float *mix, float *out, int B, int L, hipStream_
     // the 1x1 + GLU epilogue beside the float32 skip tensor (gemm_conv.h MI_FLAG_IMG4); the conv is then a stride-1 two-tap conv
     // whose taps gemm_tap.hip fetches by LDS-DMA.  The image slots no epilogue writes are the conv's zero padding: they depend
     // on the geometry (length, batch), so the images are re-zeroed when it changes.
-    const bool encimg = cfg.dtype != MI_DTYPE_F32 && x_eimg[0][0] && henc[1].conv.wtap && htenc[1].conv.wtap;
+    bool encimg = cfg.dtype != MI_DTYPE_F32 && x_eimg[0][0];
+    for (int i = 1; i < 4 && encimg; ++i) encimg = henc[i].conv.wtap && htenc[i].conv.wtap && hCh[i - 1] % 16 == 0;
     if (encimg && (eimg_L != L || eimg_B != B)) {
         for (int br = 0; br < 2; ++br)
             for (int i = 0; i < 3; ++i) MI_HIP(hipMemsetAsync(x_eimg[br][i], 0, x_eimg_floats[br][i] * sizeof(float), st));
@@ -544,81 +561,81 @@ int HModel::hforward_impl(const float *mix, float *out, int B, int L, hipStream_
     }
     // ---- layer 4: tencoder.4 (conv only) is injected into encoder.4 (Fr 8 -> 1), GroupNorm(4), deep DConv ----------
     {
-        MI_TRY(ktab(g, Gather{384, 1, 8, 1, 1, 0, 2, (int64_t)Lp[4], Lp[4]}, htenc[4].conv.Kpad, &k));
-        mi_conv_desc d = base_desc(htenc[4].conv, k, xt, (int64_t)384 * Lp[4], Geo{B, 1, Lt[4], 0, Lp[4]});
-        d.O2 = T; d.o2_valid = 0; d.S2 = 4; d.epi = MI_EPI_LINEAR; d.y = x_inject; d.y_bstride = (int64_t)768 * T; d.y_cstride = T;
+        MI_TRY(ktab(g, Gather{C3, 1, 8, 1, 1, 0, 2, (int64_t)Lp[4], Lp[4]}, htenc[4].conv.Kpad, &k));
+        mi_conv_desc d = base_desc(htenc[4].conv, k, xt, (int64_t)C3 * Lp[4], Geo{B, 1, Lt[4], 0, Lp[4]});
+        d.O2 = T; d.o2_valid = 0; d.S2 = 4; d.epi = MI_EPI_LINEAR; d.y = x_inject; d.y_bstride = (int64_t)C4 * T; d.y_cstride = T;
         MI_TRY(conv(d, stt));
         MI_TRY(join());                            // the injection and everything the waveform encoder wrote (its skips) are complete
-        taps["tenc4"] = {x_inject, (int64_t)768 * T};
-        MI_TRY(ktab(g, Gather{384, 8, 1, 1, 1, 0, 0, (int64_t)8 * Tp, Tp}, henc[4].conv.Kpad, &k));
-        mi_conv_desc e = base_desc(henc[4].conv, k, xf, (int64_t)384 * 8 * Tp, Geo{B, 8, T, 1, Tp});
+        taps["tenc4"] = {x_inject, (int64_t)C4 * T};
+        MI_TRY(ktab(g, Gather{C3, 8, 1, 1, 1, 0, 0, (int64_t)8 * Tp, Tp}, henc[4].conv.Kpad, &k));
+        mi_conv_desc e = base_desc(henc[4].conv, k, xf, (int64_t)C3 * 8 * Tp, Geo{B, 8, T, 1, Tp});
         e.O1 = 1; e.O2 = T; e.o2_valid = 0; e.S1 = 4; e.epi = MI_EPI_LINEAR; e.flags = MI_FLAG_RES; e.res = x_inject;      // output rows: exact T
-        e.y = x_zA; e.y_bstride = (int64_t)768 * T; e.y_cstride = T;
+        e.y = x_zA; e.y_bstride = (int64_t)C4 * T; e.y_cstride = T;
         MI_TRY(conv(e, st));
-        MI_TRY(group_norm(x_zA, B, 768, 4, T, T, 0, henc[4].n1w, henc[4].n1b, 0, 1, nullptr, nullptr, 0, x_a4, 768, T, T, st));
-        MI_TRY(run_deep(g, henc[4], 768, T, B, x_a4, x_b4, st));
-        MI_TRY(ktab(g, Gather{768, 1, 1, 1, 1, 0, 0, (int64_t)T, T}, henc[4].rewrite.Kpad, &k));
-        mi_conv_desc r = base_desc(henc[4].rewrite, k, x_a4, (int64_t)768 * T, Geo{B, 1, T, 0});
-        r.plain = 1; r.epi = MI_EPI_LINEAR; r.y = x_zA; r.y_bstride = (int64_t)1536 * T; r.y_cstride = T;
+        MI_TRY(group_norm(x_zA, B, C4, 4, T, T, 0, henc[4].n1w, henc[4].n1b, 0, 1, nullptr, nullptr, 0, x_a4, C4, T, T, st));
+        MI_TRY(run_deep(g, henc[4], C4, T, B, x_a4, x_b4, st));
+        MI_TRY(ktab(g, Gather{C4, 1, 1, 1, 1, 0, 0, (int64_t)T, T}, henc[4].rewrite.Kpad, &k));
+        mi_conv_desc r = base_desc(henc[4].rewrite, k, x_a4, (int64_t)C4 * T, Geo{B, 1, T, 0});
+        r.plain = 1; r.epi = MI_EPI_LINEAR; r.y = x_zA; r.y_bstride = (int64_t)C5 * T; r.y_cstride = T;
         MI_TRY(conv(r, st));
-        MI_TRY(group_norm(x_zA, B, 1536, 4, T, T, 0, henc[4].n2w, henc[4].n2b, 1, 0, nullptr, nullptr, 0, x_skip[4], 768, T, T, st));
-        taps["enc4"] = {x_skip[4], (int64_t)768 * T};
+        MI_TRY(group_norm(x_zA, B, C5, 4, T, T, 0, henc[4].n2w, henc[4].n2b, 1, 0, nullptr, nullptr, 0, x_skip[4], C4, T, T, st));
+        taps["enc4"] = {x_skip[4], (int64_t)C4 * T};
     }
     // ---- layer 5: Conv1d(768 -> 1536, k 4, s 2, p 1) on the frame axis ------------------------------------------------
     {
-        MI_TRY(ktab(g, Gather{768, 1, 4, 1, 1, 0, 1, (int64_t)T, T}, henc[5].conv.Kpad, &k));
-        mi_conv_desc d = base_desc(henc[5].conv, k, x_skip[4], (int64_t)768 * T, Geo{B, 1, T, 0});
-        d.O2 = T5; d.o2_valid = 0; d.S2 = 2; d.epi = MI_EPI_LINEAR; d.y = x_zA; d.y_bstride = (int64_t)1536 * T5; d.y_cstride = T5;
+        MI_TRY(ktab(g, Gather{C4, 1, 4, 1, 1, 0, 1, (int64_t)T, T}, henc[5].conv.Kpad, &k));
+        mi_conv_desc d = base_desc(henc[5].conv, k, x_skip[4], (int64_t)C4 * T, Geo{B, 1, T, 0});
+        d.O2 = T5; d.o2_valid = 0; d.S2 = 2; d.epi = MI_EPI_LINEAR; d.y = x_zA; d.y_bstride = (int64_t)C5 * T5; d.y_cstride = T5;
         MI_TRY(conv(d, st));
-        MI_TRY(group_norm(x_zA, B, 1536, 4, T5, T5, 0, henc[5].n1w, henc[5].n1b, 0, 1, nullptr, nullptr, 0, x_a4, 1536, T5, T5, st));
-        MI_TRY(run_deep(g, henc[5], 1536, T5, B, x_a4, x_b4, st));
-        MI_TRY(ktab(g, Gather{1536, 1, 1, 1, 1, 0, 0, (int64_t)T5, T5}, henc[5].rewrite.Kpad, &k));
-        mi_conv_desc r = base_desc(henc[5].rewrite, k, x_a4, (int64_t)1536 * T5, Geo{B, 1, T5, 0});
-        r.plain = 1; r.epi = MI_EPI_LINEAR; r.y = x_zA; r.y_bstride = (int64_t)3072 * T5; r.y_cstride = T5;
+        MI_TRY(group_norm(x_zA, B, C5, 4, T5, T5, 0, henc[5].n1w, henc[5].n1b, 0, 1, nullptr, nullptr, 0, x_a4, C5, T5, T5, st));
+        MI_TRY(run_deep(g, henc[5], C5, T5, B, x_a4, x_b4, st));
+        MI_TRY(ktab(g, Gather{C5, 1, 1, 1, 1, 0, 0, (int64_t)T5, T5}, henc[5].rewrite.Kpad, &k));
+        mi_conv_desc r = base_desc(henc[5].rewrite, k, x_a4, (int64_t)C5 * T5, Geo{B, 1, T5, 0});
+        r.plain = 1; r.epi = MI_EPI_LINEAR; r.y = x_zA; r.y_bstride = (int64_t)C6 * T5; r.y_cstride = T5;
         MI_TRY(conv(r, st));
-        MI_TRY(group_norm(x_zA, B, 3072, 4, T5, T5, 0, henc[5].n2w, henc[5].n2b, 1, 0, nullptr, nullptr, 0, x_skip[5], 1536, T5, T5, st));
-        taps["enc5"] = {x_skip[5], (int64_t)1536 * T5};
+        MI_TRY(group_norm(x_zA, B, C6, 4, T5, T5, 0, henc[5].n2w, henc[5].n2b, 1, 0, nullptr, nullptr, 0, x_skip[5], C5, T5, T5, st));
+        taps["enc5"] = {x_skip[5], (int64_t)C5 * T5};
     }
     // ---- decoder.0: input = 0 + skip (hdemucs.py:742-747) ------------------------------------------------------------
     {
-        MI_TRY(ktab(g, Gather{1536, 1, 3, 1, 1, 0, 1, (int64_t)T5, T5}, hdec[0].rewrite.Kpad, &k));
-        mi_conv_desc r = base_desc(hdec[0].rewrite, k, x_skip[5], (int64_t)1536 * T5, Geo{B, 1, T5, 0});
-        r.epi = MI_EPI_LINEAR; r.y = x_zA; r.y_bstride = (int64_t)3072 * T5; r.y_cstride = T5;
+        MI_TRY(ktab(g, Gather{C5, 1, 3, 1, 1, 0, 1, (int64_t)T5, T5}, hdec[0].rewrite.Kpad, &k));
+        mi_conv_desc r = base_desc(hdec[0].rewrite, k, x_skip[5], (int64_t)C5 * T5, Geo{B, 1, T5, 0});
+        r.epi = MI_EPI_LINEAR; r.y = x_zA; r.y_bstride = (int64_t)C6 * T5; r.y_cstride = T5;
         MI_TRY(conv(r, st));
-        MI_TRY(group_norm(x_zA, B, 3072, 4, T5, T5, 0, hdec[0].n1w, hdec[0].n1b, 1, 0, nullptr, nullptr, 0, x_pre, 1536, T5, T5, st));
+        MI_TRY(group_norm(x_zA, B, C6, 4, T5, T5, 0, hdec[0].n1w, hdec[0].n1b, 1, 0, nullptr, nullptr, 0, x_pre, C5, T5, T5, st));
         const int Lu = 2 * T5 + 2;                         // un-cropped ConvTranspose1d(k 4, s 2) output: the GroupNorm sees all of it
-        MI_TRY(ktab(g, Gather{1536, 1, 2, 1, -1, 0, 0, (int64_t)T5, T5}, hdec[0].convtr.Kpad, &k));
-        mi_conv_desc t = base_desc(hdec[0].convtr, k, x_pre, (int64_t)1536 * T5, Geo{B, 1, T5, 0});
+        MI_TRY(ktab(g, Gather{C5, 1, 2, 1, -1, 0, 0, (int64_t)T5, T5}, hdec[0].convtr.Kpad, &k));
+        mi_conv_desc t = base_desc(hdec[0].convtr, k, x_pre, (int64_t)C5 * T5, Geo{B, 1, T5, 0});
         t.O2 = T5 + 1; t.o2_valid = 0; t.epi = MI_EPI_CONVTR; t.tr_stride = 2; t.tr_pad = 0; t.out_len = Lu;
-        t.y = x_zB; t.y_cstride = Lu; t.y_bstride = (int64_t)768 * Lu;
+        t.y = x_zB; t.y_cstride = Lu; t.y_bstride = (int64_t)C4 * Lu;
         MI_TRY(conv(t, st));
         // crop [1 : 1 + T], GELU, and the next layer's `x + skip`
-        MI_TRY(group_norm(x_zB, B, 768, 4, Lu, Lu, 1, hdec[0].n2w, hdec[0].n2b, 0, 1, nullptr, x_skip[4], T, x_dec[0], 768, T, T, st));
-        taps["dec0+skip"] = {x_dec[0], (int64_t)768 * T};
+        MI_TRY(group_norm(x_zB, B, C4, 4, Lu, Lu, 1, hdec[0].n2w, hdec[0].n2b, 0, 1, nullptr, x_skip[4], T, x_dec[0], C4, T, T, st));
+        taps["dec0+skip"] = {x_dec[0], (int64_t)C4 * T};
     }
     // ---- decoder.1 (Fr 1 -> 8) and tdecoder.0 (the "empty" layer fed with decoder.1's pre-transposed-conv tensor) --------
     {
-        MI_TRY(ktab(g, Gather{768, 1, 3, 1, 1, 0, 1, (int64_t)T, T}, hdec[1].rewrite.Kpad, &k));
-        mi_conv_desc r = base_desc(hdec[1].rewrite, k, x_dec[0], (int64_t)768 * T, Geo{B, 1, T, 0});
-        r.epi = MI_EPI_LINEAR; r.y = x_zA; r.y_bstride = (int64_t)1536 * T; r.y_cstride = T;
+        MI_TRY(ktab(g, Gather{C4, 1, 3, 1, 1, 0, 1, (int64_t)T, T}, hdec[1].rewrite.Kpad, &k));
+        mi_conv_desc r = base_desc(hdec[1].rewrite, k, x_dec[0], (int64_t)C4 * T, Geo{B, 1, T, 0});
+        r.epi = MI_EPI_LINEAR; r.y = x_zA; r.y_bstride = (int64_t)C5 * T; r.y_cstride = T;
         MI_TRY(conv(r, st));
-        MI_TRY(group_norm(x_zA, B, 1536, 4, T, T, 0, hdec[1].n1w, hdec[1].n1b, 1, 0, nullptr, nullptr, 0, x_pre, 768, T, T, st));
-        MI_TRY(ktab(g, Gather{768, 2, 1, -1, 1, 0, 0, (int64_t)T, T}, hdec[1].convtr.Kpad, &k));
-        mi_conv_desc t = base_desc(hdec[1].convtr, k, x_pre, (int64_t)768 * T, Geo{B, 1, T, 1});
+        MI_TRY(group_norm(x_zA, B, C5, 4, T, T, 0, hdec[1].n1w, hdec[1].n1b, 1, 0, nullptr, nullptr, 0, x_pre, C4, T, T, st));
+        MI_TRY(ktab(g, Gather{C4, 2, 1, -1, 1, 0, 0, (int64_t)T, T}, hdec[1].convtr.Kpad, &k));
+        mi_conv_desc t = base_desc(hdec[1].convtr, k, x_pre, (int64_t)C4 * T, Geo{B, 1, T, 1});
         t.O1 = 2; t.epi = MI_EPI_CONVTR; t.flags = MI_FLAG_TR_FREQ; t.tr_stride = 4; t.tr_pad = 0; t.out_len = 8;
-        t.y = x_zB; t.y_cstride = (int64_t)8 * T; t.y_bstride = (int64_t)384 * 8 * T;
+        t.y = x_zB; t.y_cstride = (int64_t)8 * T; t.y_bstride = (int64_t)C3 * 8 * T;
         MI_TRY(conv(t, st));
         // (channel, frequency row) pairs as rows of T frames: the output and the skip carry the padded pitch Tp
-        MI_TRY(group_norm(x_zB, B, 384 * 8, 4, T, T, 0, hdec[1].n2w, hdec[1].n2b, 0, 1, nullptr, x_skip[3], Tp, x_dec[1], 384 * 8, T, Tp, st, 8));
-        taps["dec1+skip"] = {x_dec[1], (int64_t)384 * 8 * Tp};
+        MI_TRY(group_norm(x_zB, B, C3 * 8, 4, T, T, 0, hdec[1].n2w, hdec[1].n2b, 0, 1, nullptr, x_skip[3], Tp, x_dec[1], C3 * 8, T, Tp, st, 8));
+        taps["dec1+skip"] = {x_dec[1], (int64_t)C3 * 8 * Tp};
         const int Lu = 4 * T + 4;                          // un-cropped ConvTranspose1d(k 8, s 4)
-        MI_TRY(ktab(g, Gather{768, 1, 2, 1, -1, 0, 0, (int64_t)T, T}, htdec[0].convtr.Kpad, &k));
-        mi_conv_desc tt = base_desc(htdec[0].convtr, k, x_pre, (int64_t)768 * T, Geo{B, 1, T, 0});
+        MI_TRY(ktab(g, Gather{C4, 1, 2, 1, -1, 0, 0, (int64_t)T, T}, htdec[0].convtr.Kpad, &k));
+        mi_conv_desc tt = base_desc(htdec[0].convtr, k, x_pre, (int64_t)C4 * T, Geo{B, 1, T, 0});
         tt.O2 = T + 1; tt.o2_valid = 0; tt.epi = MI_EPI_CONVTR; tt.tr_stride = 4; tt.tr_pad = 0; tt.out_len = Lu;
-        tt.y = x_zA; tt.y_cstride = Lu; tt.y_bstride = (int64_t)384 * Lu;
+        tt.y = x_zA; tt.y_cstride = Lu; tt.y_bstride = (int64_t)C3 * Lu;
         MI_TRY(conv(tt, st));
-        MI_TRY(group_norm(x_zA, B, 384, 4, Lu, Lu, 2, htdec[0].n2w, htdec[0].n2b, 0, 1, nullptr, x_skip_t[3], Lp[4], x_tdec[0], 384, Lt[4], Lp[4], st));
-        taps["tdec0+skip"] = {x_tdec[0], (int64_t)384 * Lp[4]};
+        MI_TRY(group_norm(x_zA, B, C3, 4, Lu, Lu, 2, htdec[0].n2w, htdec[0].n2b, 0, 1, nullptr, x_skip_t[3], Lp[4], x_tdec[0], C3, Lt[4], Lp[4], st));
+        taps["tdec0+skip"] = {x_tdec[0], (int64_t)C3 * Lp[4]};
     }
     // ---- decoder.2-5 / tdecoder.1-4: rewrite 3x3 (k 3) + GLU -> ConvTranspose (+ GELU + next skip) -------------------------
     // Half modes (round 4, as model.hip's decoders): every tensor between these layers feeds NOTHING BUT the next matrix product
@@ -626,14 +643,16 @@ int HModel::hforward_impl(const float *mix, float *out, int B, int L, hipStream_
     // previous transposed conv's GELU + skip epilogue; for the first layer converted from GroupNorm's float32 output), and the
     // GLU output (written by the rewrite conv's epilogue, MI_FLAG_IMG) -- and both convs gather their taps by LDS-DMA
     // (gemm_tap.hip) instead of walking a table over float32 tensors.  MI_NO_TAP_IMAGE=1 restores the table-driven route.
-    const bool tapimg = cfg.dtype != MI_DTYPE_F32 && x_gimg && hdec[2].rewrite.wtap && htdec[1].rewrite.wtap && hdec[2].convtr.wtap && htdec[1].convtr.wtap;
+    bool tapimg = cfg.dtype != MI_DTYPE_F32 && x_gimg;
+    for (int j = 2; j < 6 && tapimg; ++j)        // every level has its tap-ordered weights (widths that are multiples of 8)
+        tapimg = hdec[j].rewrite.wtap && htdec[j - 1].rewrite.wtap && hdec[j].convtr.wtap && htdec[j - 1].convtr.wtap;
     // the outermost transposed conv (K = 96, bound by its output) on the image route too: no conversion pass is needed here (the GLU
     // epilogue writes the image), 38.6-38.9 against 39.3-39.5 ms; MI_H_NO_LAST_TAP=1: table-driven gather over float32
     static const bool last_tap = getenv("MI_H_NO_LAST_TAP") == nullptr;
     MI_TRY(fork());
     if (tapimg) {
-        MI_TRY(launch_f32_to_image(x_dec[1], B, 384, (int64_t)8 * Tp, cfg.dtype, x_b, st));
-        MI_TRY(launch_f32_to_image(x_tdec[0], B, 384, (int64_t)Lp[4], cfg.dtype, x_tb, stt));
+        MI_TRY(launch_f32_to_image(x_dec[1], B, C3, (int64_t)8 * Tp, cfg.dtype, x_b, st));
+        MI_TRY(launch_f32_to_image(x_tdec[0], B, C3, (int64_t)Lp[4], cfg.dtype, x_tb, stt));
     }
     for (int j = 2; j < 6; ++j) {
         const int i = 5 - j, C = hCh[i], Fr = hFr[i + 1];

@@ -111,6 +111,7 @@ size_t lstm_persist_scratch_bytes();
 size_t lstm_persist_ctl_offset();      // byte offset of the control / debug words inside the scratch block
 int launch_lstm_persist(const float *gx, const float *whh /* packed */, int N, int H, int W, float *out, void *scratch, unsigned *ctl_host,
                         hipStream_t st);
+int launch_lstm_small(const float *gx, const float *whh_natural /* (2, 4H, H) */, int N, int H, int W, float *out, hipStream_t st);   // H <= 64
 int launch_local_attn(const float *qkc, int B, int C, int T, int ld /* row pitch of qkc, % 4 == 0 */, float *out, int ld_o, hipStream_t st);
 
 // attention.hip

@@ -50,7 +50,9 @@ class HDemucsConfig:
     def validate(self) -> None:
         bad = []
         if self.audio_channels != 2: bad.append("audio_channels")
-        if self.channels != 48 or self.growth != 2: bad.append("channels/growth")
+        # channels: 48 = hdemucs_mmi (matrix-pipe LSTM / LocalState kernels); 4 = the reference's own `demucs_unittest` model
+        # (pretrained.py:27-29), same engine with the generic recurrence / attention kernels (hidden <= 32, head dimension <= 8)
+        if self.channels not in (4, 48) or self.growth != 2: bad.append("channels/growth")
         if self.nfft != 4096 or self.depth != 6: bad.append("nfft/depth")
         if self.kernel_size != 8 or self.stride != 4 or self.time_stride != 2: bad.append("kernel_size/stride/time_stride")
         if self.context != 1 or self.context_enc != 0: bad.append("context")

@@ -314,3 +314,15 @@ def test_config5_htdemucs_6s_fp16_track():
     sdrs = A.new_sdr(outs["f32"].cpu(), outs["f16"].cpu())
     print(f"htdemucs_6s fp16 track: per-source SDR vs float32 mode {[round(float(v), 1) for v in sdrs.flatten()]} dB")
     assert float(sdrs.min()) >= 44.0
+    # ... and against the FLOAT64 ORACLE (not the engine's own float32 mode) on the interior of one segment of the stitched track:
+    # samples covered by segment k alone, so the stitched value is that segment's forward
+    from oracle import htdemucs_oracle as O
+    k, stride = 11, int(0.75 * SL)
+    off, lo, hi = k * stride, SL - stride, stride
+    with torch.no_grad():
+        want = O.htdemucs_forward(O.to_torch_state(sd, torch.float64), mix[..., off:off + SL].cpu().double(), 6)[..., lo:hi]
+    got = outs["f16"][..., off + lo:off + hi].cpu().double()
+    sdr64 = 10 * torch.log10((want.pow(2).sum() + 1e-7) / ((got - want).pow(2).sum() + 1e-7))
+    f32_err = float((outs["f32"][..., off + lo:off + hi].cpu().double() - want).abs().max())
+    print(f"htdemucs_6s fp16 track, segment {k} interior vs the float64 oracle: SDR {float(sdr64):.1f} dB (float32 mode max-abs {f32_err:.2e})")
+    assert float(sdr64) >= 44.0 and f32_err <= TOL

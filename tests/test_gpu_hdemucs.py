@@ -211,6 +211,46 @@ def test_handle_outlives_many_distinct_lengths():
     assert torch.equal(m(x[..., :1100]), first)          # evicted long ago, rebuilt: same result
 
 
+def test_the_reference_unittest_model_width(golden):
+    """`demucs_unittest`, the only model the reference ships offline and the one its own CI runs, is HDemucs(channels=4)
+    (pretrained.py:27-29): the engine takes the layer widths from the weights (4 ... 128 channels; hidden 16 / 32 in the BLSTM,
+    head dimension 4 / 8 in LocalState: generic kernels), checked against the reference's forward with this repo's weights
+    (fixture `hseg_unittest_w3`: output and the deep layers' taps), in float32 and -- table routes only, the widths are no
+    multiples of 8 -- in the fp16 mode."""
+    g = golden("hseg_unittest_w3")
+    cfg = HDemucsConfig(channels=4)
+    sd = synthetic_hdemucs_state_dict(cfg, 3)
+    mix = torch.from_numpy(synth_mix(27, 220623, "tones"))[None].cuda()
+    L = mix.shape[-1]
+    T = -(-L // 1024)
+    m = HDemucs(cfg.sources, max_batch=2, channels=4)
+    m.load_state_dict(sd)
+    m.to("cuda")
+    out = m(torch.cat([mix, mix]))
+    assert torch.equal(out[0], out[1])
+    err = g.check("f64", "out", out[:1], atol=TOL)
+    g.check("f64", "enc4", m.tap("enc4", 1).view(1, 64, 1, T), atol=2e-4, rtol=2e-4)
+    g.check("f64", "enc5", m.tap("enc5", 1).view(1, 128, -(-T // 2)), atol=2e-4, rtol=2e-4)
+    g.check("f64", "tenc4", m.tap("tenc4", 1).view(1, 64, T), atol=2e-4, rtol=2e-4)
+    print(f"demucs_unittest width: max-abs vs the reference's float64 forward {err:.2e}")
+    mh = HDemucs(cfg.sources, max_batch=1, channels=4, compute_dtype="f16")
+    mh.load_state_dict(sd)
+    mh.to("cuda")
+    lo = mh(mix)
+    want = out[:1].double()
+    sdr = 10 * torch.log10(want.pow(2).sum() / (lo.double() - want).pow(2).sum())
+    print(f"demucs_unittest width, fp16 mode: SDR vs the float32 mode {float(sdr):.1f} dB")
+    assert float(sdr) >= 38.0
+    # the reference's `Separator("demucs_unittest")` plumbing (api.py:99-104, pretrained.py:64-65): resolves offline, separates a clip
+    from demucs_amd.api import Separator
+    from demucs_amd.pretrained import SOURCES, get_model
+    sep = Separator("demucs_unittest", device="cuda", shifts=0, overlap=0.25)
+    wav = mix[0].cpu().clone()
+    back, stems = sep.separate_tensor(wav)
+    assert list(stems) == SOURCES and all(v.shape == wav.shape and bool(torch.isfinite(v).all()) for v in stems.values())
+    assert torch.equal(back, wav) and get_model("demucs_unittest").cfg.channels == 4
+
+
 @pytest.mark.parametrize("mode,floor_db", [("f16", 38.0), ("bf16", 20.0)])
 def test_reduced_precision_modes_against_the_reference_autocast_floor(golden, mode, floor_db):
     """BASELINE configs[4] (hdemucs fp16) scored against the REFERENCE, not against this engine's own float32 mode:

@@ -171,6 +171,20 @@ def test_hdemucs_forward_matches_reference(golden, name, tag, dtype, atol):
     assert checked >= 23            # 6 enc + 6 dec + 5 tenc + 5 tdec + out
 
 
+def test_hdemucs_oracle_at_the_unittest_width(golden):
+    """The reference's own offline model, `demucs_unittest` = HDemucs(channels=4) (pretrained.py:27-29), with this repo's
+    deterministic weights: the oracle follows the same layer plan at any width (fixture `hseg_unittest_w3`, 216 frames)."""
+    g = golden("hseg_unittest_w3")
+    cfg = HDemucsConfig(channels=4)
+    for tag, dtype, atol in (("f64", torch.float64, 2e-9), ("f32", torch.float32, 8e-5)):
+        sd = {k: torch.from_numpy(v.copy()).to(dtype) for k, v in synthetic_hdemucs_state_dict(cfg, 3).items()}
+        taps = {}
+        with torch.no_grad():
+            out = HO.hdemucs_forward(sd, torch.from_numpy(synth_mix(27, 220623, "tones")).to(dtype)[None], hdemucs_layer_plan(cfg), 4, taps=taps)
+        taps["out"] = out
+        assert sum(1 for tap in g.taps(tag) if g.check(tag, tap, taps[tap], atol=atol, rtol=atol) is not None) >= 23
+
+
 @pytest.mark.parametrize("name,mk", [("happly_10s_seg4", lambda: synth_mix(23, 449833, "tones")),
                                      ("happly_tail10", lambda: synth_mix(26, 396910, "noise"))])      # tail chunk of 10 samples
 def test_hdemucs_apply_model_matches_reference(golden, name, mk):

@@ -254,3 +254,19 @@ def test_keyword_tables_cover_the_reference_signatures():
             assert HDemucs._FIXED[key] == default or (key == "multi_freqs" and not default), (key, default)
     assert (hfields - {"sources"}) | set(HDemucs._INERT) | set(HDemucs._FIXED) <= set(href)
     HDemucs(**{**sig["config.yaml"]["hdemucs"], "sources": ["a", "b"], "audio_channels": 2, "samplerate": 44100, "segment": 40})
+
+
+def test_pretrained_get_model_offline():
+    """demucs/pretrained.py:59-85 without the remote zoo: "demucs_unittest" (HDemucs(channels=4, sources=SOURCES), pretrained.py:27-29)
+    resolves to an engine model object with the reference's state-dict schema at that width; any other name needs a local folder."""
+    from demucs_amd.hdemucs_weights import HDemucsConfig, hdemucs_schema
+    from demucs_amd.pretrained import SOURCES, get_model
+    from demucs_amd.states import ModelLoadingError
+    m = get_model("demucs_unittest")
+    assert m.sources == SOURCES and m.cfg.channels == 4 and not hasattr(m, "valid_length")
+    assert list(m.state_dict()) == list(hdemucs_schema(HDemucsConfig(channels=4)))
+    assert m.state_dict()["encoder.5.conv.weight"].shape == (128, 64, 4)          # channels << level
+    with pytest.raises(ModelLoadingError):
+        get_model("htdemucs")
+    with pytest.raises(ModelLoadingError):
+        get_model("htdemucs", repo="/nonexistent/folder")

@@ -188,7 +188,7 @@ def hsegment_fixture(name: str, hcfg, wseed: int, mix: np.ndarray):
     store = {"meta/wseed": np.array(wseed), "meta/n_sources": np.array(len(hcfg.sources)), "meta/length": np.array(mix.shape[-1])}
     sd = synthetic_hdemucs_state_dict(hcfg, wseed)
     for tag, dtype in (("f32", torch.float32), ("f64", torch.float64)):
-        model = RefHDemucs(sources=list(hcfg.sources))
+        model = RefHDemucs(sources=list(hcfg.sources), channels=hcfg.channels)
         ref_schema = [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
         assert ref_schema == list(hdemucs_schema(hcfg).items()), "hdemucs_schema differs from the reference's state_dict"
         model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()}, strict=True)
@@ -483,6 +483,9 @@ def main():
     # stride 132 300: three full 4-second chunks and a TAIL CHUNK OF 10 SAMPLES (396 910 = 3 * 132 300 + 10)
     happly_fixture("happly_tail10", hcfg, 1, synth_mix(26, 396910, "noise"), shifts=0, split=True, overlap=0.25, segment=4)
     hautocast_fixture("hautocast_10s_w0", hcfg, 0, synth_mix(21, 441000, "tones"))
+    # the reference's own offline model: pretrained.get_model("demucs_unittest") = HDemucs(channels=4, sources=SOURCES) (pretrained.py:27-29),
+    # here with this repo's deterministic weights; 220 623 samples = 216 frames: the BLSTM runs in two overlapping chunks at layer 4
+    hsegment_fixture("hseg_unittest_w3", HDemucsConfig(channels=4), 3, synth_mix(27, 220623, "tones"))
     print("checkpoint package / keyword / clip fixtures")
     package_fixture("pkg_htdemucs", "htdemucs", 5, synth_mix(31, 150000, "tones"))
     package_fixture("pkg_hdemucs", "hdemucs", 6, synth_mix(32, 88200, "noise"))
