@@ -71,6 +71,8 @@ def force_collectives():
         _forced = old
 
 
+# DEMUCS_AMD_SHARD_PIPELINE=0: one all-gather of whole slabs after all forwards (round 3's schedule) instead of one per batched forward
+_pipelined = os.environ.get("DEMUCS_AMD_SHARD_PIPELINE", "1") != "0"
 _timing = None          # a list while `collect_timing()` is active: one tuple of device events per sharded call
 
 
@@ -208,6 +210,10 @@ def apply_model_sharded(model, mix: torch.Tensor, shifts: int = 0, overlap: floa
     single = n_pass == 1 and not shifts and not bag
 
     ev0 = _mark(device)
+    if single and _pipelined and kinds[0] in ("segments", "generic") and (world > 1 or (_forced and dist.is_initialized())):
+        return _single_pass_pipelined(models[0], kinds[0], mix, device, group, world, rank, intervals, last_owner, slab_lo, slab_hi,
+                                      segment_length, stride, weight, overlap, transition_power, segment, S, channels, callback, cb_arg,
+                                      lock, ev0)
     contrib = torch.zeros(batch, rows, max_slab, device=device, dtype=torch.float32)
     if engine:
         valid = max([_apply._leaf_valid_length(m, segment_length, segment) for m, k in zip(models, kinds) if k == "segments"],
@@ -327,6 +333,124 @@ def apply_model_sharded(model, mix: torch.Tensor, shifts: int = 0, overlap: floa
     if ev0 is not None:
         _timing.append((ev0, ev1, ev2, _mark(device)))
     return total
+
+
+def _single_pass_pipelined(sub, kind, mix, device, group, world, rank, intervals, last_owner, slab_lo, slab_hi, segment_length, stride,
+                           weight, overlap, transition_power, segment, S, channels, callback, cb_arg, lock, ev0):
+    """One pass of a plain model (no bag, no shifts) with the exchange PIPELINED under the forwards.
+
+    A rank runs its segments in groups of `max_batch` (one batched forward each).  After group g the part of its slab in front of
+    group g + 1's first segment is final -- no later segment reaches back over it -- so that chunk is all-gathered at once
+    (asynchronously: RCCL on its own stream) while the next group's forward runs; only the last chunk's exchange is exposed.  Every
+    rank derives every rank's chunk plan from the offset list alone, so all ranks issue the same collectives with the same
+    (padded) sizes.  The chunks are stitched as the whole slabs were (copied; the seam with the previous rank's tail added) and
+    the track is divided by the summed weights afterwards: the same sums in the same order as the one-shot exchange and as one GPU.
+    With 8 ranks on the 60-minute track (77 segments per rank = forwards of 32 + 32 + 13) five sixths of the 4.5 GB each rank
+    receives move under compute."""
+    batch, _, length = mix.shape
+    rows = S * channels
+    offsets = list(range(0, length, stride))
+    per = max(1, int(getattr(sub, "max_batch", 4)))
+    plans = []                      # per rank: (its groups of offsets, chunk bounds in slab coordinates)
+    for r, (a, b) in enumerate(intervals):
+        n = slab_hi[r] - slab_lo[r]
+        own = [o for o in offsets if a <= o and (o < b or r == last_owner)] if n else []
+        groups = [own[i:i + per] for i in range(0, len(own), per)]
+        bounds = ([0] + [g[0] - slab_lo[r] for g in groups[1:]] + [n]) if groups else [0]
+        plans.append((groups, bounds))
+    G = max(len(p[0]) for p in plans)
+    groups, bounds = plans[rank]
+    my_len = slab_hi[rank] - slab_lo[rank]
+    nccl = dist.get_backend(group) == "nccl"
+    if kind == "segments":
+        valid = _apply._leaf_valid_length(sub, segment_length, segment)
+        i_lo, i_hi = intervals[rank]
+        w_lo = max(0, i_lo - valid)
+        w_hi = min(length, (length if rank == last_owner else i_hi + segment_length) + 2 * valid)
+        window = mix[:, :, w_lo:w_hi].to(device=device, dtype=torch.float32).contiguous() if my_len else None
+    else:
+        padded_mix = _apply.tensor_chunk(mix).padded(length)
+    sub.to(device)
+    sub.eval()
+    for _ in range(rng_draws_per_forward(sub) * len(offsets)):
+        random.randrange(1)          # transformer.py:680, once per segment forward of the pass, on EVERY rank (see apply_model_sharded)
+    arg = _apply._with(cb_arg, model_idx_in_bag=0, shift_idx=0)
+
+    def fire(state, v):
+        if callback is not None:
+            with lock:
+                callback(_apply._with(arg, segment_offset=v, state=state))
+
+    v0 = slab_lo[rank]
+    parts = [torch.zeros(rows, my_len, device=device, dtype=torch.float32) for _ in range(batch)] if my_len else []
+    pending = []                    # (work, send buffer, receive buffer)
+    for g in range(G):
+        if g < len(groups):
+            for b in range(batch):
+                listen = b == 0 and callback is not None
+                on_start, on_end = ((lambda v: fire("start", v)), (lambda v: fire("end", v))) if listen else (None, None)
+                if kind == "segments":
+                    _apply.device_split_accumulate(sub, window[b], 0, length, groups[g], segment_length, valid, weight, parts[b], v0,
+                                                   on_start, on_end, draw_rng=False, base_origin=w_lo)
+                else:
+                    kw = dict(shifts=0, split=False, overlap=overlap, transition_power=transition_power, device=device, segment=segment)
+                    with no_sharding():
+                        for v in groups[g]:
+                            chunk = _apply.TensorChunk(padded_mix, v, segment_length)
+                            if b == 0:
+                                fire("start", v)
+                            state = random.getstate()                     # the pass's draws were taken above, on every rank
+                            out = _apply.apply_model(sub, chunk, **kw)[b].reshape(rows, -1).to(device)
+                            random.setstate(state)
+                            if b == 0:
+                                fire("end", v)
+                            lo = v - v0
+                            a, c = max(lo, 0), min(lo + out.shape[-1], my_len)
+                            parts[b][:, a:c] += weight[a - lo:c - lo] * out[:, a - lo:c - lo]
+        sizes = [p[1][g + 1] - p[1][g] if g < len(p[0]) else 0 for p in plans]
+        width = max(sizes)
+        send = torch.empty(batch, rows, width, device=device, dtype=torch.float32)
+        if sizes[rank]:
+            for b in range(batch):
+                send[b, :, :sizes[rank]] = parts[b][:, bounds[g]:bounds[g + 1]]
+        recv = torch.empty(world, batch, rows, width, device=device, dtype=torch.float32)
+        if nccl:
+            work = dist.all_gather_into_tensor(recv, send, group=group, async_op=True)      # RCCL over xGMI, under the next forward
+        else:
+            work = dist.all_gather(list(recv.unbind(0)), send, group=group, async_op=True)
+        pending.append((work, send, recv))
+    del parts
+    ev1 = _mark(device)
+    for work, _, _ in pending:
+        work.wait()
+    ev2 = _mark(device)
+    # stitch in rank order, chunks in order: a piece only overlaps what lies in front of it (the previous rank's tail)
+    total = torch.empty(batch, rows, length, device=device, dtype=torch.float32)
+    done = 0
+    for r, (r_groups, r_bounds) in enumerate(plans):
+        for g in range(len(r_groups)):
+            s0, s1 = slab_lo[r] + r_bounds[g], slab_lo[r] + r_bounds[g + 1]
+            if s1 <= s0:
+                continue
+            src = pending[g][2][r]
+            if s0 > done:
+                total[:, :, done:s0].zero_()
+                done = s0
+            head = min(done, s1)
+            if head > s0:
+                total[:, :, s0:head] += src[:, :, :head - s0]
+            if s1 > head:
+                total[:, :, head:s1] = src[:, :, head - s0:s1 - s0]
+            done = max(done, s1)
+    if done < length:
+        total[:, :, done:].zero_()
+    del pending
+    engine = kind == "segments"
+    for b in range(batch):
+        _normalise(total[b], 0, length, offsets, segment_length, weight, engine)
+    if ev0 is not None:
+        _timing.append((ev0, ev1, ev2, _mark(device)))
+    return total.view(batch, S, channels, length)
 
 
 def _normalise(acc: torch.Tensor, acc_origin: int, length: int, offsets: Sequence[int], segment_length: int,

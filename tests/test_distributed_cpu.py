@@ -33,9 +33,12 @@ def _worker(rank, world, port, length, overlap, out_path, case):
     batch = 2 if case == "batch2" else 1
     mix = torch.randn(batch, 2, length, generator=torch.Generator().manual_seed(7))
     events = []
-    if case in ("plain", "batch2", "ragged"):
+    if case in ("plain", "batch2", "ragged", "plain_mb2"):
         Toy = RaggedToy if case == "ragged" else ToyModel        # ragged: no valid_length, every chunk at its own length (HDemucs)
-        got = apply_model_sharded(Toy(), mix, overlap=overlap, callback=lambda d: events.append(dict(d)))
+        model = Toy()
+        if case == "plain_mb2":
+            model.max_batch = 2          # groups of two segments: several pipelined all-gathers per rank, unequal group counts
+        got = apply_model_sharded(model, mix, overlap=overlap, callback=lambda d: events.append(dict(d)))
         with no_sharding():
             want = P.apply_model(Toy(), mix, shifts=0, split=True, overlap=overlap)
         ok = torch.equal(got, want)                        # single pass: bit-identical
@@ -73,6 +76,7 @@ def _worker(rank, world, port, length, overlap, out_path, case):
 
 @pytest.mark.parametrize("world,length,overlap,case", [
     (2, 2500, 0.25, "plain"), (2, 300, 0.25, "plain"), (3, 4001, 0.1, "plain"), (2, 1700, 0.25, "batch2"), (2, 1337, 0.25, "ragged"),
+    (2, 5000, 0.25, "plain_mb2"), (3, 5333, 0.25, "plain_mb2"), (3, 650, 0.25, "plain_mb2"),
     (2, 2500, 0.25, "shifts"), (3, 3111, 0.25, "bag_shifts"), (2, 390, 0.25, "bag_shifts"),
     # shifts=1 (the default of apply_model and Separator) and a one-member bag with non-unit weights must NOT take the
     # single-pass shortcut; a model that draws nothing per forward (HDemucs) must not advance the RNG per segment
@@ -84,7 +88,7 @@ def test_sharded_equals_single_process(tmp_path, world, length, overlap, case):
     res = torch.load(out_path)
     assert res["ok"], res
     assert res["shape"] == (2 if case == "batch2" else 1, 3, 2, length)
-    if case in ("plain", "batch2", "ragged"):       # every segment fired its start/end pair on exactly one rank
+    if case in ("plain", "batch2", "ragged", "plain_mb2"):       # every segment fired its start/end pair on exactly one rank
         assert res["events"] == 2 * len(range(0, length, int((1 - overlap) * 400)))
 
 
