@@ -311,7 +311,8 @@ def main():
                                     "per batched forward, random-init weights (synthetic_state_dict seed 0)"
                                     + ("; the SAME fixed track at every N > 1 (strong scaling); N = 1 of that curve is "
                                        "`fixed_track` in the N = 1 line" if multi else "")),
-                       "parallelism": (f"segments sharded over {world} GPUs by track interval, one RCCL all-gather of stem slabs per step"
+                       "parallelism": (f"segments sharded over {world} GPUs by track interval, RCCL all-gather of the stem slabs over xGMI, one "
+                                       "asynchronous piece per batched forward under the next forward"
                                        if multi else "one GPU")},
             "roofline": {"bound": bound, "kernel": dom["name"], "achieved": round(achieved, 2), "peak": peak,
                          "unit": unit, "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,

@@ -15,7 +15,9 @@ the weighted overlap-add (apply.py:295-299), so:
     the rank's contribution slab: the bag and shift averages are accumulated on the device;
   * ONE all-gather of the equally padded contribution slabs (RCCL over xGMI) per call, whatever
     the number of bag members and shifts; every rank adds the slabs into the full-track buffer in
-    rank order.
+    rank order.  A single pass of a plain model (no bag, no shifts) pipelines that exchange: one
+    asynchronous all-gather per batched forward, of the part of the slab that forward completed,
+    under the next forward (`_single_pass_pipelined`).
 With a single pass of a plain model (no bag, shifts=0) the slabs are gathered un-normalised and divided after
 the stitch: with overlap <= 0.5 a sample is covered by at most two segments, so the float32
 result is then bit-identical to the single-GPU (and to the reference's sequential) order.  With
