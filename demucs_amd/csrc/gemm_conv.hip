@@ -584,7 +584,13 @@ int launch_conv(const mi_conv_desc &din, hipStream_t st) {
                "conv: MI_FLAG_HEADS needs a half-precision LINEAR layer on tokens (O1 = 1) with M %% 512 == 0 and an aligned output");
     MI_REQUIRE(!d.xh || d.half, "conv: an operand-image input needs a half-precision layer");
     if (d.half) return launch_conv_half(d, tile, plain, st);
-    if (!plain && dmatap_eligible(d, tile)) return launch_dmatap<MI_EPI_GLU>(d, tile, st);
+    // small batches: a k x k GLU conv whose 128-row tiles under-fill the chip (B = 1: 6 x 21 workgroups) takes 96-row tiles
+    static const int small_tile = getenv("MI_SMALL_TILE") ? atoi(getenv("MI_SMALL_TILE")) : 1;
+    int ktile = tile;
+    if (small_tile && !plain && d.epi == MI_EPI_GLU && tile == 128 && d.Mpad % 96 == 0 &&
+        (int64_t)(d.Mpad / 128) * ceil_div((int64_t)d.B * d.O1 * d.O2, BN) < 200)
+        ktile = 96;
+    if (!plain && dmatap_eligible(d, ktile)) return launch_dmatap<MI_EPI_GLU>(d, ktile, st);
     static const int x6_mode = getenv("MI_X6_MODE") ? atoi(getenv("MI_X6_MODE")) : 0;   // bisecting: 1 plain only, 2 gather only
     static const int x6_class = getenv("MI_X6_CLASS") ? atoi(getenv("MI_X6_CLASS")) : -1;   // bisecting: one kernel class only
     if (x6_class >= 0 && x6_class != d.epi * 8 + (tile == 32 ? 0 : tile == 64 ? 1 : tile == 96 ? 2 : 3) * 2 + (plain ? 1 : 0)) d.wx = nullptr;

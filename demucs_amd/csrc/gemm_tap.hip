@@ -203,14 +203,16 @@ static int launch_tap_cfg(const mi_conv_desc &d, hipStream_t st) {
 // d validated by launch_conv (gemm_conv.hip): half mode, stride-1 conv (the strided encoder convs arrive as stride-1 two-tap convs on
 // a phase-split image, gemm_conv.h MI_FLAG_IMG4), input image + tap-ordered weights; epilogues GLU, transposed-conv scatter, bias + GELU
 int launch_conv_tap(const mi_conv_desc &d, int tile, hipStream_t st) {
-    const bool lin_gelu = d.epi == MI_EPI_LINEAR && (d.flags & (MI_FLAG_GELU | MI_FLAG_SCALE | MI_FLAG_RES | MI_FLAG_LN | MI_FLAG_IMG | MI_FLAG_HEADS | MI_FLAG_STATS)) == MI_FLAG_GELU;
-    MI_REQUIRE((d.epi == MI_EPI_GLU || d.epi == MI_EPI_CONVTR || lin_gelu) && d.S1 == 1 && d.S2 == 1,
-               "conv tap: instantiated for stride-1 GLU convs, transposed convs and bias + GELU convs");
+    const int lflags = d.flags & (MI_FLAG_GELU | MI_FLAG_SCALE | MI_FLAG_RES | MI_FLAG_LN | MI_FLAG_IMG | MI_FLAG_HEADS | MI_FLAG_STATS);
+    const bool lin_gelu = d.epi == MI_EPI_LINEAR && lflags == MI_FLAG_GELU;
+    const bool lin_bias = d.epi == MI_EPI_LINEAR && lflags == 0;        // hdemucs layers 4 / 5: k = 3 convs followed by a GroupNorm pass
+    MI_REQUIRE((d.epi == MI_EPI_GLU || d.epi == MI_EPI_CONVTR || lin_gelu || lin_bias) && d.S1 == 1 && d.S2 == 1,
+               "conv tap: instantiated for stride-1 GLU convs, transposed convs and bias (+ GELU) convs");
     MI_REQUIRE(d.wtap && d.xh && d.ntaps >= 1 && d.tap_k2 >= 1 && d.K % (8 * d.ntaps) == 0 && (((uintptr_t)d.wtap | (uintptr_t)d.xh) & 15) == 0,
                "conv tap: needs the tap-ordered weight image, the input image and K = Cin * ntaps with Cin %% 8 == 0");
     MI_REQUIRE(d.xh_n >= (int64_t)d.B * d.D1 * (d.x_ld ? d.x_ld : d.D2), "conv tap: input image has %lld positions", (long long)d.xh_n);
 #define MI_TAP_E(W1, W2, T1, T2, E, F) (d.half == MI_DTYPE_BF16 ? launch_tap_cfg<MI_DTYPE_BF16, W1, W2, T1, T2, E, F>(d, st) : launch_tap_cfg<MI_DTYPE_F16, W1, W2, T1, T2, E, F>(d, st))
-#define MI_TAP(W1, W2, T1, T2) (d.epi == MI_EPI_GLU ? MI_TAP_E(W1, W2, T1, T2, MI_EPI_GLU, 0) : d.epi == MI_EPI_CONVTR ? MI_TAP_E(W1, W2, T1, T2, MI_EPI_CONVTR, 0) : MI_TAP_E(W1, W2, T1, T2, MI_EPI_LINEAR, MI_FLAG_GELU))
+#define MI_TAP(W1, W2, T1, T2) (d.epi == MI_EPI_GLU ? MI_TAP_E(W1, W2, T1, T2, MI_EPI_GLU, 0) : d.epi == MI_EPI_CONVTR ? MI_TAP_E(W1, W2, T1, T2, MI_EPI_CONVTR, 0) : lin_bias ? MI_TAP_E(W1, W2, T1, T2, MI_EPI_LINEAR, 0) : MI_TAP_E(W1, W2, T1, T2, MI_EPI_LINEAR, MI_FLAG_GELU))
     switch (tile) {
         case 128: return MI_TAP(2, 2, 2, 2);
         case 96: return MI_TAP(1, 4, 3, 1);

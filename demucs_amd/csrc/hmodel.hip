@@ -52,7 +52,7 @@ int HModel::load_deep(const WeightTable &wt, const std::string &prefix, int C, H
     const std::string p = prefix + ".dconv.layers." + std::to_string(d);
     const float *w, *b;
     MI_TRY(wt.get(p + ".0.weight", (int64_t)H * C * 3, &w)); MI_TRY(wt.get(p + ".0.bias", H, &b));
-    MI_TRY(pack_conv(w, b, H, 3 * C, false, &l->conv3));
+    MI_TRY(pack_conv(w, b, H, 3 * C, false, &l->conv3, 3));         // half modes: + the tap-ordered image
     MI_TRY(load_norm(wt, p + ".1", H, &l->g1w, &l->g1b));
     for (int layer = 0; layer < 2; ++layer) {          // nn.LSTM(bidirectional, 2 layers): gate rows i, f, g, o
         const int Kin = layer ? 2 * H : H;
@@ -174,7 +174,7 @@ int HModel::hinit(const mi_config &c, const mi_tensor_desc *weights, size_t n) {
     }
     // decoder.0 (mirror of encoder.5): Conv1d k3 -> GN -> GLU -> ConvTranspose1d(k4, s2) -> GN -> crop -> GELU
     MI_TRY(wt.get("decoder.0.rewrite.weight", (int64_t)C6 * C5 * 3, &rw)); MI_TRY(wt.get("decoder.0.rewrite.bias", C6, &rb));
-    MI_TRY(pack_conv(rw, rb, C6, C5 * 3, false, &hdec[0].rewrite));
+    MI_TRY(pack_conv(rw, rb, C6, C5 * 3, false, &hdec[0].rewrite, 3));
     MI_TRY(load_norm(wt, "decoder.0.norm1", C6, &hdec[0].n1w, &hdec[0].n1b));
     MI_TRY(wt.get("decoder.0.conv_tr.weight", (int64_t)C5 * C4 * 4, &w)); MI_TRY(wt.get("decoder.0.conv_tr.bias", C4, &b));
     MI_TRY(pack_convtr(w, b, C5, C4, &hdec[0].convtr, 2));
@@ -184,7 +184,7 @@ int HModel::hinit(const mi_config &c, const mi_tensor_desc *weights, size_t n) {
         std::vector<float> mid((size_t)C5 * C4 * 3);
         for (size_t mc = 0; mc < (size_t)C5 * C4; ++mc)
             for (int k2 = 0; k2 < 3; ++k2) mid[mc * 3 + k2] = rw[mc * 9 + 3 + k2];
-        MI_TRY(pack_conv(mid.data(), rb, C5, C4 * 3, false, &hdec[1].rewrite));
+        MI_TRY(pack_conv(mid.data(), rb, C5, C4 * 3, false, &hdec[1].rewrite, 3));
         MI_TRY(load_norm(wt, "decoder.1.norm1", C5, &hdec[1].n1w, &hdec[1].n1b));
         MI_TRY(wt.get("decoder.1.conv_tr.weight", (int64_t)C4 * C3 * 8, &w)); MI_TRY(wt.get("decoder.1.conv_tr.bias", C3, &b));
         MI_TRY(pack_convtr(w, b, C4, C3, &hdec[1].convtr, 4));
@@ -366,6 +366,10 @@ int HModel::run_lstm(const float *gx, const float *whh, int N, int H, int W, flo
 int HModel::run_deep(HGeo &g, HEncW &e, int C, int Tn, int B, float *x, float *tmp, hipStream_t st) {
     const int H = C / 4;
     const Geo gt{B, 1, Tn, 0};
+    // half modes: the k = 3 convs of layers 4 / 5 and of decoders 0 / 1 (K up to 4 608) on the tap-DMA route of gemm_tap.hip, their
+    // float32 inputs converted to operand images by one streaming pass each (MI_H_NO_DEEP_TAP=1: table-driven gathers)
+    static const bool no_deep_tap = getenv("MI_H_NO_DEEP_TAP") != nullptr;
+    const bool deep_tap = cfg.dtype != MI_DTYPE_F32 && !no_deep_tap;
     float *src = x, *dst = tmp;
     for (int d = 0; d < 2; ++d) {
         const HDeepLayerW &l = e.deep[d];
@@ -374,6 +378,10 @@ int HModel::run_deep(HGeo &g, HEncW &e, int C, int Tn, int B, float *x, float *t
         MI_TRY(ktab(g, Gather{C, 1, 3, 1, dil, 0, dil, (int64_t)Tn, Tn}, l.conv3.Kpad, &k));
         mi_conv_desc c3 = base_desc(l.conv3, k, src, (int64_t)C * Tn, gt);
         c3.epi = MI_EPI_LINEAR; c3.y = x_dh; c3.y_bstride = (int64_t)H * Tn; c3.y_cstride = Tn;
+        if (deep_tap && l.conv3.wtap) {          // K = 3 C = 2 304 / 4 608: the taps of a 16-bit image of the layer input, by LDS-DMA
+            MI_TRY(launch_f32_to_image(src, B, C, Tn, cfg.dtype, x_zB, st));
+            c3.xh = x_zB; c3.xh_n = (int64_t)B * Tn; c3.wtap = l.conv3.wtap; c3.ntaps = 3; c3.tap_k2 = 3; c3.tap_pad2 = dil; c3.tap_dil2 = dil;
+        }
         MI_TRY(conv(c3, st));
         MI_TRY(group_norm(x_dh, B, H, 1, Tn, Tn, 0, l.g1w, l.g1b, 0, 1, nullptr, nullptr, 0, x_dy1, H, Tn, Tn, st));
         // ---- BLSTM(hidden, layers = 2, max_steps = 200, skip) ------------------------------------------------------
@@ -601,6 +609,11 @@ int HModel::hforward_impl(const float *mix, float *out, int B, int L, hipStream_
         MI_TRY(ktab(g, Gather{C5, 1, 3, 1, 1, 0, 1, (int64_t)T5, T5}, hdec[0].rewrite.Kpad, &k));
         mi_conv_desc r = base_desc(hdec[0].rewrite, k, x_skip[5], (int64_t)C5 * T5, Geo{B, 1, T5, 0});
         r.epi = MI_EPI_LINEAR; r.y = x_zA; r.y_bstride = (int64_t)C6 * T5; r.y_cstride = T5;
+        static const bool no_deep_tap = getenv("MI_H_NO_DEEP_TAP") != nullptr;
+        if (cfg.dtype != MI_DTYPE_F32 && !no_deep_tap && hdec[0].rewrite.wtap) {
+            MI_TRY(launch_f32_to_image(x_skip[5], B, C5, T5, cfg.dtype, x_zB, st));
+            r.xh = x_zB; r.xh_n = (int64_t)B * T5; r.wtap = hdec[0].rewrite.wtap; r.ntaps = 3; r.tap_k2 = 3; r.tap_pad2 = 1;
+        }
         MI_TRY(conv(r, st));
         MI_TRY(group_norm(x_zA, B, C6, 4, T5, T5, 0, hdec[0].n1w, hdec[0].n1b, 1, 0, nullptr, nullptr, 0, x_pre, C5, T5, T5, st));
         const int Lu = 2 * T5 + 2;                         // un-cropped ConvTranspose1d(k 4, s 2) output: the GroupNorm sees all of it
@@ -618,6 +631,11 @@ int HModel::hforward_impl(const float *mix, float *out, int B, int L, hipStream_
         MI_TRY(ktab(g, Gather{C4, 1, 3, 1, 1, 0, 1, (int64_t)T, T}, hdec[1].rewrite.Kpad, &k));
         mi_conv_desc r = base_desc(hdec[1].rewrite, k, x_dec[0], (int64_t)C4 * T, Geo{B, 1, T, 0});
         r.epi = MI_EPI_LINEAR; r.y = x_zA; r.y_bstride = (int64_t)C5 * T; r.y_cstride = T;
+        static const bool no_deep_tap = getenv("MI_H_NO_DEEP_TAP") != nullptr;
+        if (cfg.dtype != MI_DTYPE_F32 && !no_deep_tap && hdec[1].rewrite.wtap) {
+            MI_TRY(launch_f32_to_image(x_dec[0], B, C4, T, cfg.dtype, x_zB, st));
+            r.xh = x_zB; r.xh_n = (int64_t)B * T; r.wtap = hdec[1].rewrite.wtap; r.ntaps = 3; r.tap_k2 = 3; r.tap_pad2 = 1;
+        }
         MI_TRY(conv(r, st));
         MI_TRY(group_norm(x_zA, B, C5, 4, T, T, 0, hdec[1].n1w, hdec[1].n1b, 1, 0, nullptr, nullptr, 0, x_pre, C4, T, T, st));
         MI_TRY(ktab(g, Gather{C4, 2, 1, -1, 1, 0, 0, (int64_t)T, T}, hdec[1].convtr.Kpad, &k));

@@ -13,8 +13,15 @@
  *     data_ptr()), contiguous float32 unless stated; `stream` is a hipStream_t (NULL = the
  *     default stream).  All work is enqueued asynchronously on `stream`; no call synchronises
  *     the device except mi_model_create / mi_model_destroy.
- *   - a handle is single-stream: do not use one handle from two streams/threads at once;
- *     different handles are independent.
+ *   - a handle is single-stream: do not use one handle from two streams/threads at once.
+ *   - PROCESS-WIDE STATE (one process per GPU is the deployment).  Handles are independent EXCEPT for: (1) the activation
+ *     workspace of the htdemucs engine, which every handle created on the same device with the same (n_sources,
+ *     segment_length, max_batch, float32 / half) shares -- a bag of four fine-tuned models holds its ~0.57 GB per batched
+ *     segment once: such handles must run one after the other on one stream (what apply_model's bag loop does), never
+ *     concurrently; hdemucs handles own their workspace; (2) the schedule switches mi_set_two_streams / mi_set_istft_fused
+ *     and the MI_* environment variables (read once); (3) two small device blocks every launch may use: a 256-float sink for
+ *     masked stores and 256 bytes of zeros (the source of out-of-frame LDS-DMA transfers).  A forward also uses a side stream
+ *     owned by its handle; it is joined on the caller's stream before the call returns.
  */
 #ifndef DEMUCS_AMD_H
 #define DEMUCS_AMD_H
