@@ -48,6 +48,7 @@ class MiConvDesc(C.Structure):
         ("xh", C.c_void_p), ("xh_n", C.c_int64), ("yh", C.c_void_p), ("yh_n", C.c_int64),
         ("wtap", C.c_void_p), ("ntaps", C.c_int32), ("tap_k2", C.c_int32), ("tap_pad1", C.c_int32), ("tap_pad2", C.c_int32),
         ("tap_dil1", C.c_int32), ("tap_dil2", C.c_int32), ("yh_pq", C.c_int64),
+        ("dma_rows", C.c_int32), ("dma_rows_pad", C.c_int32),
     ]
 
 

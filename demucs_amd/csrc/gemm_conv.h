@@ -112,6 +112,10 @@ typedef struct mi_conv_desc {
     int32_t ntaps, tap_k2, tap_pad1, tap_pad2; /* K1 * K2 taps, K2 columns per kernel row, padding along d1 / d2                  */
     int32_t tap_dil1, tap_dil2;                /* tap step along d1 / d2: 0 = 1; -1 for the two taps of a transposed conv (input q - j) */
     int64_t yh_pq;                             /* MI_FLAG_IMG4: positions per item and plane of the phase-split output image        */
+    int32_t dma_rows;       /* float32 layers: 1 = the caller vouches that EVERY entry of `ktab` has d2 == 0 (taps move along rows only:
+                               strided frequency-axis convs, frequency-axis transposed convs): admits the LDS-DMA main loop of
+                               conv_gemm_dmarow_kernel (bit-identical results); 0 = table-driven gather                              */
+    int32_t dma_rows_pad;
 } mi_conv_desc;
 
 #ifdef __cplusplus

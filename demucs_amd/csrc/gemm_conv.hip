@@ -390,6 +390,161 @@ static int launch_dmatap(const mi_conv_desc &d, int tile, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// LDS-DMA main loop for float32 layers whose taps move along ROWS only (every table entry has d2 == 0, S2 == 1): the frequency
+// branch's strided encoder convs (k = 8, s = 4 along the frequency axis: row 4 o1 + j - 2), its transposed convs as two-tap GEMMs
+// (rows q, q - 1) and every 1x1 layer that does not run conv_gemm_dma_kernel (GLU / GroupNorm-GLU epilogues, 96- and 64-row
+// tiles).  Row k of a K step's B tile is then a run of an input row at the SAME columns as the output tile, 16-byte chunks at
+// aligned positions: no shifted runs, no zero-padding fix-up, never an address outside the tensor (a tap whose row lies outside
+// [0, D1), a column past the end and the K padding read the zero page).  The row offsets come from the gather table -- one
+// SCALAR 64-byte load per wave and K step (its four rows' entries; lgkmcnt, so the counted vmcnt waits of the transfer ring stay
+// exact) -- which keeps ONE kernel per (tile, epilogue) for all of these layers.  Summation order = conv_gemm_kernel's: results
+// are bit-identical to the table-driven route (tests/test_gpu_kernels.py).  Round 3 ran these classes at 0.5-0.6 of the fp32 MFMA
+// peak (8 dword gathers + bounds tests + ds_writes per thread and K step, or float4 loads staged through registers).
+template <int BMT, int EPI, int LFLAGS>
+__global__ __launch_bounds__(256, 3) void conv_gemm_dmarow_kernel(const mi_conv_desc d, const int N, const int MT, const int Gm) {
+    constexpr int BM = BMT, WM = BM == 128 ? 2 : 1, WN = 4 / WM, TM = BM / (32 * WM), TN = BN / (32 * WN);
+    constexpr int SS = BK * (BM + BN);                       // floats per stage: A image then B image
+    __shared__ __attribute__((aligned(16))) float smem[3 * SS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    int mt, nt;
+    if (!tile_of_block(MT, Gm, N, mt, nt)) return;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int P = d.O1 * d.O2;
+    const int o2v = d.o2_valid ? d.o2_valid : d.O2;
+    const int x_ld = d.x_ld ? d.x_ld : d.D2;
+    const float *zero = d.sink + 256;
+
+    // ---- A: the [16][BM] image of a K step is BM / 16 transfers of 1 KiB: BM = 128: two per wave (two 128-float rows each);
+    //      BM = 96: six (waves 0, 1 two, waves 2, 3 one); BM = 64: one per wave.  Transfer q moves floats [256 q, 256 q + 256)
+    constexpr int NA = BM == 64 ? 1 : 2;
+    const bool a2 = BM == 128 || (BM == 96 && wave < 2);
+    int a_row[NA], a_col[NA], a_lds[NA];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+        const int q = j ? 4 + wave : wave, f = 256 * q + 4 * lane;
+        a_row[j] = f / BM; a_col[j] = f % BM; a_lds[j] = 256 * q;
+    }
+    // ---- B: rows 4 wave + 2 j + (lane >> 5), 16 bytes at column 4 (lane & 31) ---------------------------------------------------
+    const int c4 = (lane & 31) * 4, lh = lane >> 5;
+    const ColInfo lc = decompose(n0 + c4, N, P, d.O2, o2v);
+    const int i1b = lc.o1 * d.S1;
+    const float *xcol = d.x + (size_t)lc.b * d.x_bstride + (size_t)i1b * x_ld + lc.o2;
+    const int4 *ktab4 = reinterpret_cast<const int4 *>(d.ktab) + 4 * wave;       // (off, d1, d2, ci) of this wave's four rows
+    // (off, d1) of rows 4 wave .. 4 wave + 3 of K step kt into SGPRs.  Inline asm: hipcc turns these uniform loads into VMEM loads
+    // inside the loop (the DMA builtins count as stores that might alias the table) and then waits vmcnt(0) for them -- which
+    // drains the transfer ring every K step
+    typedef int v2i __attribute__((ext_vector_type(2)));
+    v2i e0, e1, e2, e3;
+#define MI_ROW_ENTRIES(kt)                                                                                           \
+    asm volatile("s_load_dwordx2 %0, %4, 0x0\n\ts_load_dwordx2 %1, %4, 0x10\n\ts_load_dwordx2 %2, %4, 0x20\n\t"          \
+                 "s_load_dwordx2 %3, %4, 0x30\n\ts_waitcnt lgkmcnt(0)"                                               \
+                 : "=&s"(e0), "=&s"(e1), "=&s"(e2), "=&s"(e3) : "s"(ktab4 + (kt) * BK) : "memory")
+
+#define MI_ROWDMA_TILE(kt, stage)                                                                                   \
+    do {                                                                                                            \
+        float *sa = smem + (stage) * SS, *sb = sa + BK * BM + (4 * wave) * BN;                                      \
+        _Pragma("unroll") for (int j = 0; j < NA; ++j)                                                              \
+            if (j == 0 || a2) {                                                                                     \
+                const float *ga = d.wt + (size_t)((kt) * BK + a_row[j]) * d.Mpad + m0 + a_col[j];                   \
+                __builtin_amdgcn_global_load_lds((gvoid_t *)ga, (lvoid_t *)(sa + a_lds[j]), 16, 0, 0);              \
+            }                                                                                                       \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                             \
+            const int off = j ? (lh ? e3.x : e2.x) : (lh ? e1.x : e0.x), dd1 = j ? (lh ? e3.y : e2.y) : (lh ? e1.y : e0.y); \
+            const bool ok = lc.valid && (unsigned)(i1b + dd1) < (unsigned)d.D1;                                     \
+            __builtin_amdgcn_global_load_lds((gvoid_t *)(ok ? xcol + off : zero), (lvoid_t *)(sb + 2 * j * BN), 16, 0, 0); \
+        }                                                                                                           \
+    } while (0)
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int nk = d.Kpad / BK;
+    const int li = lane & 31;
+    MI_ROW_ENTRIES(0);
+    MI_ROWDMA_TILE(0, 0);
+    if (nk > 1) { MI_ROW_ENTRIES(1); MI_ROWDMA_TILE(1, 1); }
+    int stage = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        // the table rows of K step kt + 2: their latency passes under the wait for tile kt and the barrier
+        if (kt + 2 < nk) MI_ROW_ENTRIES(kt + 2);
+        // tile kt has landed once all but this wave's newest tile (3 or 4 transfers) are done -- for every wave
+        if (kt + 1 < nk) {
+            if (BM == 64 || (BM == 96 && !a2)) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        // stage (kt+2)%3 == (kt-1)%3 was last read in the previous iteration, which every wave has finished
+        if (kt + 2 < nk) MI_ROWDMA_TILE(kt + 2, stage == 0 ? 2 : stage - 1);
+        const float *As = smem + stage * SS, *Bs = As + BK * BM;
+        float af[2][TM], bf[2][TN];
+#pragma unroll
+        for (int a = 0; a < TM; ++a) af[0][a] = As[lh * BM + (wm * TM + a) * 32 + li];
+#pragma unroll
+        for (int b = 0; b < TN; ++b) bf[0][b] = Bs[lh * BN + (wn * TN + b) * 32 + li];
+#pragma unroll
+        for (int s = 0; s < BK / 2; ++s) {
+            if (s + 1 < BK / 2) {
+#pragma unroll
+                for (int a = 0; a < TM; ++a) af[(s + 1) & 1][a] = As[(2 * (s + 1) + lh) * BM + (wm * TM + a) * 32 + li];
+#pragma unroll
+                for (int b = 0; b < TN; ++b) bf[(s + 1) & 1][b] = Bs[(2 * (s + 1) + lh) * BN + (wn * TN + b) * 32 + li];
+            }
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s & 1][a], bf[s & 1][b], acc[a][b], 0, 0, 0);
+        }
+        constexpr int kReads = (TM == 2 ? 1 : TM) + (TN == 2 ? 1 : TN);
+        __builtin_amdgcn_sched_group_barrier(0x100, kReads, 0);
+#pragma unroll
+        for (int s = 0; s < BK / 2; ++s) {
+            if (s + 1 < BK / 2) __builtin_amdgcn_sched_group_barrier(0x100, kReads, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
+        }
+        stage = stage == 2 ? 0 : stage + 1;
+    }
+#undef MI_ROWDMA_TILE
+#undef MI_ROW_ENTRIES
+    conv_epilogue<TM, TN, EPI, LFLAGS>(d, acc, m0, n0, wm, wn, N, P, o2v);
+}
+
+// float32 layer with row taps only (the caller vouches for the table: `dma_rows`; a plain layer's table is the identity): see above
+static bool dmarow_eligible(const mi_conv_desc &d, int tile, bool plain) {
+    static const bool off = getenv("MI_NO_DMA_ROWS") != nullptr;
+    const int ld = d.x_ld ? d.x_ld : d.D2;
+    const int lf = d.flags & (MI_FLAG_GELU | MI_FLAG_SCALE | MI_FLAG_RES | MI_FLAG_LN | MI_FLAG_STATS | MI_FLAG_IMG | MI_FLAG_IMG4 | MI_FLAG_HEADS);
+    // 1x1 + GLU / GroupNorm-GLU: 128-row tiles only -- the 96-row ones are the level-0 / 1 rewrites (K = 48 / 96: three or six K steps,
+    // bound by their output), where the register-staged kernel's four workgroups per CU measured 3 % faster (476 vs 490 us)
+    const bool epi_ok = (d.epi == MI_EPI_LINEAR && lf == MI_FLAG_GELU && !plain) || d.epi == MI_EPI_CONVTR ||
+                        ((d.epi == MI_EPI_GLU || d.epi == MI_EPI_GN_GLU) && plain && tile == 128 && !(d.flags & (MI_FLAG_IMG | MI_FLAG_IMG4)));
+    return !off && !d.half && !d.wx && d.ktab && epi_ok && (plain || d.dma_rows) && (tile == 64 || tile == 96 || tile == 128) &&
+           d.Mpad % tile == 0 && d.S2 == 1 && d.O2 == ld && ld % 4 == 0 && ((uintptr_t)d.x & 3) == 0 && ((uintptr_t)d.ktab & 63) == 0 &&
+           (d.epi == MI_EPI_CONVTR || tile != 64 || d.epi == MI_EPI_LINEAR);
+}
+template <int EPI, int LFLAGS>
+static int launch_dmarow(const mi_conv_desc &d, int tile, hipStream_t st) {
+    const int64_t N64 = (int64_t)d.B * d.O1 * d.O2;
+    MI_REQUIRE(N64 < (1ll << 31) - 256 && d.Mpad % tile == 0, "conv: DMA row route: %lld positions, Mpad %d", (long long)N64, d.Mpad);
+    const int N = (int)N64, MT = d.Mpad / tile, NT = ceil_div(N, BN);
+    const unsigned grid = grouped_grid(MT, NT, 1);
+    if (tile == 128) hipLaunchKernelGGL((conv_gemm_dmarow_kernel<128, EPI, LFLAGS>), dim3(grid), dim3(256), 0, st, d, N, MT, 1);
+    else if constexpr (EPI == MI_EPI_LINEAR || EPI == MI_EPI_CONVTR) {
+        if (tile == 96) hipLaunchKernelGGL((conv_gemm_dmarow_kernel<96, EPI, LFLAGS>), dim3(grid), dim3(256), 0, st, d, N, MT, 1);
+        else hipLaunchKernelGGL((conv_gemm_dmarow_kernel<64, EPI, LFLAGS>), dim3(grid), dim3(256), 0, st, d, N, MT, 1);
+    } else return set_error(MI_EINVAL, "conv: DMA row route has no %d-row tile for epilogue %d", tile, EPI);
+    MI_CHECK_LAUNCH();
+    return MI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 template <int WM, int WN, int TM, int TN, int EPI, int LFLAGS, bool PLAIN>
 static int launch_cfg(const mi_conv_desc &d, hipStream_t st) {
     constexpr int BM = WM * TM * 32;
@@ -591,6 +746,14 @@ int launch_conv(const mi_conv_desc &din, hipStream_t st) {
         (int64_t)(d.Mpad / 128) * ceil_div((int64_t)d.B * d.O1 * d.O2, BN) < 200)
         ktile = 96;
     if (!plain && dmatap_eligible(d, ktile)) return launch_dmatap<MI_EPI_GLU>(d, ktile, st);
+    if (dmarow_eligible(d, tile, plain)) {
+        switch (d.epi) {
+            case MI_EPI_LINEAR: return launch_dmarow<MI_EPI_LINEAR, MI_FLAG_GELU>(d, tile, st);
+            case MI_EPI_CONVTR: return launch_dmarow<MI_EPI_CONVTR, 0>(d, tile, st);
+            case MI_EPI_GLU: return launch_dmarow<MI_EPI_GLU, 0>(d, tile, st);
+            case MI_EPI_GN_GLU: return launch_dmarow<MI_EPI_GN_GLU, 0>(d, tile, st);
+        }
+    }
     static const int x6_mode = getenv("MI_X6_MODE") ? atoi(getenv("MI_X6_MODE")) : 0;   // bisecting: 1 plain only, 2 gather only
     static const int x6_class = getenv("MI_X6_CLASS") ? atoi(getenv("MI_X6_CLASS")) : -1;   // bisecting: one kernel class only
     if (x6_class >= 0 && x6_class != d.epi * 8 + (tile == 32 ? 0 : tile == 64 ? 1 : tile == 96 ? 2 : 3) * 2 + (plain ? 1 : 0)) d.wx = nullptr;

@@ -547,6 +547,7 @@ int HModel::hforward_impl(const float *mix, float *out, int B, int L, hipStream_
             mi_conv_desc d = base_desc(henc[i].conv, k, xf, Cin * Pin, gin);
             d.O1 = hFr[i + 1]; d.S1 = 4; d.epi = MI_EPI_LINEAR; d.flags = MI_FLAG_GELU;
             d.y = x_a; d.y_bstride = C * P; d.y_cstride = P;
+            d.dma_rows = 1;                    // taps along the frequency axis only
             if (i && encimg) {                 // rows o1, o1 + 1 of every plane of the previous level's image
                 const int Q = hFr[i] / 4 + 1;
                 d.xh = x_eimg[0][i - 1]; d.xh_n = (int64_t)B * Q * Tp; d.wtap = henc[i].conv.wtap; d.ntaps = 2; d.tap_k2 = 1;
@@ -694,6 +695,7 @@ int HModel::hforward_impl(const float *mix, float *out, int B, int L, hipStream_
             mi_conv_desc t = base_desc(hdec[j].convtr, k, x_a, C * P, gg);
             t.O1 = Fr + 1; t.epi = MI_EPI_CONVTR; t.flags = MI_FLAG_TR_FREQ; t.out_len = 4 * Fr;
             t.y_cstride = (int64_t)4 * Fr * Tp; t.y_bstride = Cout * t.y_cstride; t.y = x_dec[j];
+            t.dma_rows = 1;                    // rows q and q - 1
             if (!last) { t.flags |= MI_FLAG_GELU | MI_FLAG_RES; t.res = x_skip[i - 1]; }
             if (!last && tapimg) { t.flags |= MI_FLAG_IMG; t.yh = x_dec[j]; t.yh_n = (int64_t)B * t.y_cstride; }
             if (tr_tap) { t.xh = x_gimg; t.xh_n = (int64_t)B * P; t.wtap = hdec[j].convtr.wtap; t.ntaps = 2; t.tap_k2 = 1; t.tap_dil1 = -1; }

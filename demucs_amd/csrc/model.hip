@@ -961,6 +961,7 @@ int Model::run_core_impl(const float *mix, const float *mag, int B, hipStream_t 
             mi_conv_desc d = base_desc(enc[i].conv, enc[i].ktab_conv, xf, Cin * Pin, gin);
             d.O1 = kFr[i + 1]; d.S1 = 4; d.epi = MI_EPI_LINEAR; d.flags = MI_FLAG_GELU;
             d.y = w_a; d.y_bstride = C * P; d.y_cstride = P;
+            d.dma_rows = 1;                  // taps along the frequency axis only (float32: LDS-DMA main loop, gemm_conv.hip)
             if (i && enc[i].conv.wtap && w_eimg[0][i - 1]) {
                 // the previous level's output as a phase-split image: a stride-1 two-tap conv over its slots (rows o1, o1 + 1)
                 const int Q = kFr[i] / 4 + 1;
@@ -1068,6 +1069,7 @@ int Model::run_core_impl(const float *mix, const float *mag, int B, hipStream_t 
             mi_conv_desc t = base_desc(dec[j].convtr, dec[j].ktab_tr, w_a, C * P, g);
             t.O1 = Fr + 1; t.epi = MI_EPI_CONVTR; t.flags = MI_FLAG_TR_FREQ; t.out_len = 4 * Fr;
             t.y_cstride = (int64_t)4 * Fr * T; t.y_bstride = Cout * t.y_cstride;
+            t.dma_rows = 1;                  // rows q and q - 1
             if (last) t.y = w_yspec;
             else { t.flags |= MI_FLAG_GELU | MI_FLAG_RES; t.res = w_skip[2 - j]; t.y = din; }
             if (!last && tapimg) { t.flags |= MI_FLAG_IMG; t.yh = din; t.yh_n = (int64_t)B * t.y_cstride; }

@@ -228,6 +228,112 @@ def test_float32_k3_glu_time_branch_on_the_dma_tap_route(lib):
     assert bool(torch.isfinite(got).all()) and maxerr(got, want) < 2e-5
 
 
+def _conv_desc_call(lib, **kw):
+    d = _lib.MiConvDesc()
+    for name, _ in _lib.MiConvDesc._fields_:
+        v = kw.get(name, 0)
+        setattr(d, name, v.data_ptr() if isinstance(v, torch.Tensor) else v)
+    _lib.check(lib.mi_conv_forward(C.byref(d), stream()), "mi_conv_forward")
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("Cout,Fr,T,pitch", [(96, 64, 48, 48), (128, 16, 336, 336), (48, 32, 61, 64), (192, 8, 37, 40)])
+def test_float32_strided_frequency_conv_on_the_dma_row_route(lib, Cout, Fr, T, pitch):
+    """Round 4: float32 layers whose taps move along rows only (`dma_rows`) run an LDS-DMA main loop (gemm_conv.hip
+    conv_gemm_dmarow_kernel; 128-, 96- and 64-row tiles) -- here the encoder's Conv2d k=(8,1) s=(4,1) p=(2,0) + GELU
+    (hdemucs.py:110,136,144).  Against F.conv2d in float64 and, bit for bit, against the table-driven gather (same products, same
+    k order); with a row pitch wider than the valid width the padding columns hold NaN and must never reach a valid output."""
+    B, Cin = 2, 24
+    x, W, b = rnd(B, Cin, Fr, T, seed=41), rnd(Cout, Cin, 8, 1, seed=42, scale=0.1), rnd(Cout, seed=43)
+    want = F.gelu(F.conv2d(x, W, b, stride=(4, 1), padding=(2, 0)))
+    wt, bias, M, Mpad, K, Kpad, tile = pack_w(W.reshape(Cout, -1), b)
+    assert tile in (64, 96, 128)
+    xp = torch.full((B, Cin, Fr, pitch), float("nan"))
+    xp[..., :T] = x.float()
+    xin = xp.cuda().contiguous()
+    kt = ktab(Cin, 8, 1, 1, 1, 2, 0, Fr * pitch, pitch, Kpad)
+    P = Fr // 4 * pitch
+    outs = []
+    for rows in (1, 0):
+        y = torch.full((B, Cout, Fr // 4, pitch), float("nan"), device="cuda")
+        _conv_desc_call(lib, wt=wt, M=M, Mpad=Mpad, K=K, Kpad=Kpad, ktab=kt, x=xin, x_bstride=Cin * Fr * pitch, B=B, D1=Fr, D2=T, O1=Fr // 4,
+                        O2=pitch, S1=4, S2=1, row_mode=1, epi=EPI_LINEAR, flags=FLAG_GELU, bias=bias, y=y, y_bstride=Cout * P, y_cstride=P,
+                        tile_m=tile, o2_valid=T if pitch != T else 0, x_ld=pitch if pitch != T else 0, dma_rows=rows)
+        outs.append(y[..., :T].cpu())
+    assert bool(torch.isfinite(outs[0]).all())
+    assert maxerr(outs[0], want) < 2e-5
+    assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("Co,skip_on", [(32, True), (24, True), (16, False), (48, False)])
+def test_float32_frequency_transposed_conv_on_the_dma_row_route(lib, Co, skip_on):
+    """ConvTranspose2d k=(8,1) s=(4,1) + crop (+ GELU + skip) as the 4-phase GEMM with its two taps (rows q, q - 1) by LDS-DMA:
+    M = 4 Co = 128 / 96 / 64 / 192 rows.  Float64 reference and bit identity with the table-driven gather."""
+    B, Cc, Fr, T = 2, 40, 9, 132
+    x, W, b = rnd(B, Cc, Fr, T, seed=44), rnd(Cc, Co, 8, 1, seed=45, scale=0.2), rnd(Co, seed=46)
+    skip = rnd(B, Co, 4 * Fr, T, seed=47)
+    want = F.conv_transpose2d(x, W, b, stride=(4, 1))[..., 2:-2, :]
+    if skip_on:
+        want = F.gelu(want) + skip
+    Wr = W.reshape(Cc, Co, 8)
+    W2 = torch.zeros(4 * Co, 2 * Cc, dtype=torch.float64)       # row 4co+r, col 2ci+j  <- W[ci][co][r+4j]
+    for r in range(4):
+        for j in range(2):
+            W2[r::4, j::2] = Wr[:, :, r + 4 * j].t()
+    wt, bias, M, Mpad, K, Kpad, tile = pack_w(W2, b.repeat_interleave(4))
+    assert tile in (64, 96, 128)
+    kt = ktab(Cc, 2, 1, -1, 1, 0, 0, Fr * T, T, Kpad)
+    xin, res = x.float().cuda().contiguous(), skip.float().cuda().contiguous()
+    outs = []
+    for rows in (1, 0):
+        y = torch.full((B, Co, 4 * Fr, T), float("nan"), device="cuda")
+        _conv_desc_call(lib, wt=wt, M=M, Mpad=Mpad, K=K, Kpad=Kpad, ktab=kt, x=xin, x_bstride=Cc * Fr * T, B=B, D1=Fr, D2=T, O1=Fr + 1, O2=T,
+                        S1=1, S2=1, row_mode=1, epi=EPI_CONVTR, flags=FLAG_TR_FREQ | (FLAG_GELU | FLAG_RES if skip_on else 0),
+                        res=res if skip_on else 0, bias=bias, y=y, y_bstride=Co * 4 * Fr * T, y_cstride=4 * Fr * T, out_len=4 * Fr,
+                        tile_m=tile, dma_rows=rows)
+        outs.append(y.cpu())
+    assert maxerr(outs[0], want) < 2e-5
+    assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("Cc,gn", [(64, False), (128, False), (192, True)])
+def test_float32_pointwise_glu_layers_on_the_dma_row_route(lib, Cc, gn):
+    """1x1 conv + GLU (the encoders' rewrite, hdemucs.py:117,149-150; with the frequency embedding's additive table) and the DConv
+    tail 1x1 -> GroupNorm -> GLU -> LayerScale -> + x (demucs.py:141-143,151-154) as plain layers: 96- / 128-row tiles of the
+    LDS-DMA row loop.  Float64 reference; bit identity with the table-driven gather (the same layer declared non-plain)."""
+    B, Fr, T = 2, 6, 140
+    P = Fr * T
+    K = 32 if gn else Cc
+    x, W, b = rnd(B, K, Fr, T, seed=48), rnd(2 * Cc, K, 1, 1, seed=49, scale=0.2), rnd(2 * Cc, seed=50)
+    z = F.conv2d(x, W, b)
+    wt, bias, M, Mpad, K_, Kpad, tile = pack_w(W.reshape(2 * Cc, K), b, glu=True)
+    assert tile == 128 and K_ == Kpad
+    kt = ktab(K, 1, 1, 1, 1, 0, 0, P, T, Kpad)
+    xin = x.float().cuda().contiguous()
+    extra = {}
+    if gn:
+        g2w, g2b, ls, res = 1 + 0.2 * rnd(2 * Cc, seed=51), 0.1 * rnd(2 * Cc, seed=52), 1 + 0.3 * rnd(Cc, seed=53), rnd(B, Cc, Fr, T, seed=54)
+        rows = z.permute(0, 2, 1, 3).reshape(B * Fr, 2 * Cc, T)
+        mean, var = rows.mean(dim=(1, 2)), rows.var(dim=(1, 2), unbiased=False)
+        st2 = torch.stack([mean, 1.0 / torch.sqrt(var + 1e-5)], 1).float().cuda().contiguous()
+        zn = F.group_norm(rows, 1, g2w, g2b, eps=1e-5).view(B, Fr, 2 * Cc, T).permute(0, 2, 1, 3)
+        want = res + ls[None, :, None, None] * F.glu(zn, dim=1)
+        extra = dict(epi=EPI_GN_GLU, gn_stats=st2, gn_w=pack_vec(g2w, Mpad, glu=True), gn_b=pack_vec(g2b, Mpad, glu=True),
+                     scale=ls.float().cuda(), res=res.float().cuda().contiguous())
+    else:
+        emb = rnd(Cc, Fr, seed=55)
+        want = F.glu(z, dim=1) + emb[None, :, :, None]
+        extra = dict(epi=EPI_GLU, flags=FLAG_EMB, emb=emb.float().cuda().contiguous())
+    outs = []
+    for plain in (1, 0):
+        y = torch.full((B, Cc, Fr, T), float("nan"), device="cuda")
+        _conv_desc_call(lib, wt=wt, M=M, Mpad=Mpad, K=K, Kpad=Kpad, ktab=kt, x=xin, x_bstride=K * P, B=B, D1=Fr, D2=T, O1=Fr, O2=T, S1=1, S2=1,
+                        row_mode=1, bias=bias, y=y, y_bstride=Cc * P, y_cstride=P, tile_m=tile, plain=plain, **extra)
+        outs.append(y.cpu())
+    assert maxerr(outs[0], want) < (1e-4 if gn else 2e-5)
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_linear_scale_residual_big_k(lib, x6):
     """nn.Linear on channel-first tokens with LayerScale + residual epilogue (transformer.py:364-367):
     M=512, K=2048 exercises the 128-row tile and a long contraction."""

@@ -181,14 +181,16 @@ def test_model_rejects_cpu_and_bad_shapes():
 
 @pytest.mark.skipif(os.environ.get("MI_X6") is not None or os.environ.get("MI_DCONV_ROW") is not None, reason="already inside the re-run")
 def test_non_default_kernel_switches_keep_parity():
-    """Two opt-in kernel routes, re-run together in ONE fresh process (both switches are read once, at packing / first launch;
+    """Non-default kernel routes, re-run together in ONE fresh process (the switches are read once, at packing / first launch;
     they touch disjoint layers):
       * MI_X6=1 (gemm_x6.hip: fp32 operands as three exact bf16 terms, six bf16 MFMA products, fp32 accumulate) on the
         transformer / 1x1 layers -- single process, as DESIGN.md section 8 requires for this mode;
       * MI_DCONV_ROW=lds (dconv_row.hip `dconv_rowlds_kernel`: the C = 48 frequency rows stay in LDS across both residual
-        layers; slower than the per-wave kernel, kept selectable).
+        layers; slower than the per-wave kernel, kept selectable);
+      * MI_NO_DMA_TAP=1 / MI_NO_DMA_ROWS=1: the float32 k x k, strided and transposed convs back on the table-driven gather of
+        conv_gemm_kernel (round 3's route, which the LDS-DMA main loops replaced by default).
     The reference-golden and float64-oracle parity tests above must hold unchanged."""
-    env = dict(os.environ, MI_X6="1", MI_X6_MODE="1", MI_DCONV_ROW="lds")
+    env = dict(os.environ, MI_X6="1", MI_X6_MODE="1", MI_DCONV_ROW="lds", MI_NO_DMA_TAP="1", MI_NO_DMA_ROWS="1")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k",
                         "reference_golden or float64_oracle", "-p", "no:cacheprovider"], env=env, capture_output=True, text=True,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
