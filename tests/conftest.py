@@ -10,8 +10,33 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+def _usable_cores():
+    """Threads the CPU side of the tests (the oracles) may use: the affinity mask capped by the cgroup CPU quota and by 16.  A GPU
+    box shows all 256 logical CPUs of its host to a job that owns a 16-core share: torch's default of one thread per visible CPU
+    makes every small float64 matmul of an oracle a 256-thread fork/join against the quota (the 400-step LSTM reference took 29 s)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 16))
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
+    n = _usable_cores()
+    os.environ.setdefault("OMP_NUM_THREADS", str(n))          # child processes (re-runs under other switches, rank launches)
+    try:
+        import torch
+        if torch.get_num_threads() > n:
+            torch.set_num_threads(n)
+    except ImportError:
+        pass
 
 
 class Golden:
