@@ -34,6 +34,10 @@ def klass(name):
     m = re.search(r"conv_gemm_dmatap_kernel<(\d+), (\d+), (\d+)>", name)      # round 4: LDS-DMA main loop of the float32 k x k GLU convs
     if m:
         return f"conv_gemm<{EPI[int(m.group(2))]},tile{m.group(1)}>"
+    m = re.search(r"conv_gemm_dmarow_kernel<(\d+), (\d+), (\d+)>", name)      # round 4: LDS-DMA main loop of the float32 row-tap layers
+    if m:
+        epi = int(m.group(2))
+        return f"conv_gemm<{EPI[epi]},tile{m.group(1)}{',1x1' if epi in (1, 4) else ''}>"      # GLU / GroupNorm-GLU run it as plain 1x1 layers only
     m = re.search(r"conv_gemm_x6_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (true|false)>", name)
     if m:
         wm, wn, tm, tn, epi, _, plain = m.groups()
@@ -55,7 +59,7 @@ def klass(name):
     return None
 
 
-DMA_TAP = set()        # classes seen running conv_gemm_dmatap_kernel
+DMA_TAP = set()        # classes seen running conv_gemm_dmatap_kernel / conv_gemm_dmarow_kernel (16-byte DMA runs)
 
 
 def collect(d, counter):
@@ -65,7 +69,7 @@ def collect(d, counter):
             if r["Counter_Name"] != counter:
                 continue
             k = klass(r["Kernel_Name"])
-            if k and "conv_gemm_dmatap_kernel" in r["Kernel_Name"]:
+            if k and ("conv_gemm_dmatap_kernel" in r["Kernel_Name"] or "conv_gemm_dmarow_kernel" in r["Kernel_Name"]):
                 DMA_TAP.add(k)
             if k:
                 out[k][0] += 1
