@@ -106,6 +106,7 @@ SIGNATURES = {
     "mi_layernorm_cf": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p]),
     "mi_debug_set_post_launch_hook": (None, [C.c_void_p]),
+    "mi_debug_last_conv_route": (C.c_int, []),
     "mi_last_error": (C.c_char_p, []),
     "mi_version": (C.c_char_p, []),
 }

@@ -10,6 +10,7 @@
 namespace mi {
 
 post_launch_hook_t g_post_launch_hook = nullptr;
+int g_last_conv_route = -1;
 
 char *last_error_buf() {
     static thread_local char buf[1024] = "";
@@ -57,6 +58,7 @@ extern "C" {
 
 const char *mi_last_error(void) { return last_error_buf(); }
 void mi_debug_set_post_launch_hook(void (*hook)(void *stream)) { g_post_launch_hook = hook; }
+int mi_debug_last_conv_route(void) { return g_last_conv_route; }
 const char *mi_version(void) { return "demucs_amd 0.1 gfx950"; }
 
 int mi_model_create(const mi_config *cfg, const mi_tensor_desc *weights, size_t n_weights, void **handle) {

@@ -28,6 +28,7 @@ int set_error(int code, const char *fmt, ...);
 // consumes state it did not write (what a co-resident process of another application would leave behind).
 typedef void (*post_launch_hook_t)(void *stream);
 extern post_launch_hook_t g_post_launch_hook;
+extern int g_last_conv_route;          // mi_debug_last_conv_route (include/demucs_amd.h)
 
 #define MI_CHECK_LAUNCH()                                                   \
     do {                                                                    \

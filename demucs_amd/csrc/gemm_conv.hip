@@ -381,6 +381,7 @@ static int launch_dmatap(const mi_conv_desc &d, int tile, hipStream_t st) {
     MI_REQUIRE(N64 < (1ll << 31) - 256 && d.Mpad % tile == 0, "conv: DMA tap route: %lld positions, Mpad %d", (long long)N64, d.Mpad);
     const int N = (int)N64, MT = d.Mpad / tile, NT = ceil_div(N, BN);
     const unsigned grid = grouped_grid(MT, NT, 1);
+    g_last_conv_route = 2;
     if (tile == 128 && d.ntaps == 9) hipLaunchKernelGGL((conv_gemm_dmatap_kernel<128, EPI, 9>), dim3(grid), dim3(256), 0, st, d, N, MT, 1);
     else if (tile == 128) hipLaunchKernelGGL((conv_gemm_dmatap_kernel<128, EPI, 3>), dim3(grid), dim3(256), 0, st, d, N, MT, 1);
     else if (d.ntaps == 9) hipLaunchKernelGGL((conv_gemm_dmatap_kernel<96, EPI, 9>), dim3(grid), dim3(256), 0, st, d, N, MT, 1);
@@ -535,6 +536,7 @@ static int launch_dmarow(const mi_conv_desc &d, int tile, hipStream_t st) {
     MI_REQUIRE(N64 < (1ll << 31) - 256 && d.Mpad % tile == 0, "conv: DMA row route: %lld positions, Mpad %d", (long long)N64, d.Mpad);
     const int N = (int)N64, MT = d.Mpad / tile, NT = ceil_div(N, BN);
     const unsigned grid = grouped_grid(MT, NT, 1);
+    g_last_conv_route = 3;
     if (tile == 128) hipLaunchKernelGGL((conv_gemm_dmarow_kernel<128, EPI, LFLAGS>), dim3(grid), dim3(256), 0, st, d, N, MT, 1);
     else if constexpr (EPI == MI_EPI_LINEAR || EPI == MI_EPI_CONVTR) {
         if (tile == 96) hipLaunchKernelGGL((conv_gemm_dmarow_kernel<96, EPI, LFLAGS>), dim3(grid), dim3(256), 0, st, d, N, MT, 1);
@@ -561,11 +563,13 @@ static int launch_cfg(const mi_conv_desc &d, hipStream_t st) {
     if constexpr (PLAIN && BM == 128 && EPI == MI_EPI_LINEAR) {
         static const bool use_dma = getenv("MI_NO_DMA") == nullptr;
         if (use_dma) {
+            g_last_conv_route = 1;
             hipLaunchKernelGGL((conv_gemm_dma_kernel<EPI, LFLAGS>), dim3(grid), dim3(256), 0, st, d, N, MT, Gm);
             MI_CHECK_LAUNCH();
             return MI_OK;
         }
     }
+    g_last_conv_route = 0;
     hipLaunchKernelGGL((conv_gemm_kernel<WM, WN, TM, TN, EPI, LFLAGS, PLAIN>), dim3(grid), dim3(256), 0, st, d, N, MT, Gm);
     MI_CHECK_LAUNCH();
     return MI_OK;
@@ -733,12 +737,12 @@ int launch_conv(const mi_conv_desc &din, hipStream_t st) {
     MI_REQUIRE(!(d.flags & MI_FLAG_IMG) || d.epi != MI_EPI_CONVTR ||
                (d.half && d.yh && d.yh_n >= (int64_t)d.B * d.y_cstride && ((uintptr_t)d.yh & 15) == 0),
                "conv: MI_FLAG_IMG on a transposed conv needs a half mode and an output image of >= B * y_cstride positions");
-    if (d.wtap) { MI_REQUIRE(d.half && d.xh, "conv: tap-ordered weights need a half mode and an operand-image input"); return launch_conv_tap(d, tile, st); }
+    if (d.wtap) { MI_REQUIRE(d.half && d.xh, "conv: tap-ordered weights need a half mode and an operand-image input"); g_last_conv_route = 6; return launch_conv_tap(d, tile, st); }
     MI_REQUIRE(!(d.flags & MI_FLAG_HEADS) || (d.half && d.yh && d.epi == MI_EPI_LINEAR && d.M % 512 == 0 && d.O1 == 1 && d.yh_n >= d.O2 &&
                                               ((uintptr_t)d.yh & 15) == 0 && !(d.flags & MI_FLAG_IMG)),
                "conv: MI_FLAG_HEADS needs a half-precision LINEAR layer on tokens (O1 = 1) with M %% 512 == 0 and an aligned output");
     MI_REQUIRE(!d.xh || d.half, "conv: an operand-image input needs a half-precision layer");
-    if (d.half) return launch_conv_half(d, tile, plain, st);
+    if (d.half) { g_last_conv_route = 5; return launch_conv_half(d, tile, plain, st); }
     // small batches: a k x k GLU conv whose 128-row tiles under-fill the chip (B = 1: 6 x 21 workgroups) takes 96-row tiles
     static const int small_tile = getenv("MI_SMALL_TILE") ? atoi(getenv("MI_SMALL_TILE")) : 1;
     int ktile = tile;

@@ -322,6 +322,7 @@ bool conv_x6_supported(int tile) { return tile == 128 || tile == 96 || tile == 6
 
 // d has been validated by launch_conv (gemm_conv.hip), which also decided `plain`
 int launch_conv_x6(const mi_conv_desc &d, int tile, bool plain, hipStream_t st) {
+    g_last_conv_route = 4;
     MI_REQUIRE(d.wx && ((uintptr_t)d.wx & 15) == 0, "conv x6: split weight image missing or misaligned");
 #define MI_DISPATCH(E)                                              \
     case E: return plain ? launch_tile_x6<E, 0, true>(d, tile, st) : launch_tile_x6<E, 0, false>(d, tile, st)

@@ -284,6 +284,13 @@ int mi_layernorm_cf(const float *x_dev, int32_t B, int32_t C, int32_t T, const f
  * tools/micro/poison_all.py to interleave a register / LDS poisoning kernel between the engine's kernels. */
 void mi_debug_set_post_launch_hook(void (*hook)(void *stream));
 
+/* Debug aid for the kernel tests: which main loop the LAST mi_conv_forward of this process took -- 0 table-driven gather /
+ * register-staged loader (conv_gemm_kernel), 1 LDS-DMA plain linear tile (conv_gemm_dma_kernel), 2 LDS-DMA shifted-run taps
+ * (conv_gemm_dmatap_kernel), 3 LDS-DMA row taps (conv_gemm_dmarow_kernel), 4 split-bf16 (gemm_x6.hip), 5 half-mode loops
+ * (gemm_half.hip), 6 half-mode tap images (gemm_tap.hip); -1 before any call.  A route is chosen from the descriptor alone, so a
+ * test that compares two routes bit for bit also has to see that they WERE two routes.  Process-wide, not thread-safe. */
+int mi_debug_last_conv_route(void);
+
 const char *mi_last_error(void);
 /* "demucs_amd <version> gfx950" */
 const char *mi_version(void);

@@ -196,6 +196,7 @@ def test_float32_3x3_glu_on_the_dma_tap_route(lib, Cc, Fr, T, pitch):
             setattr(d, name, v.data_ptr() if isinstance(v, torch.Tensor) else v)
         _lib.check(lib.mi_conv_forward(C.byref(d), stream()), "mi_conv_forward")
         torch.cuda.synchronize()
+        assert lib.mi_debug_last_conv_route() == (2 if geo else 0)       # shifted-run DMA taps / table-driven gather
         outs.append(y[..., :T].cpu())
     assert bool(torch.isfinite(outs[0]).all())
     assert maxerr(outs[0], want) < 2e-5
@@ -224,6 +225,7 @@ def test_float32_k3_glu_time_branch_on_the_dma_tap_route(lib):
         setattr(d, name, v.data_ptr() if isinstance(v, torch.Tensor) else v)
     _lib.check(lib.mi_conv_forward(C.byref(d), stream()), "mi_conv_forward")
     torch.cuda.synchronize()
+    assert lib.mi_debug_last_conv_route() == 2
     got = y[..., :L].cpu()
     assert bool(torch.isfinite(got).all()) and maxerr(got, want) < 2e-5
 
@@ -235,6 +237,7 @@ def _conv_desc_call(lib, **kw):
         setattr(d, name, v.data_ptr() if isinstance(v, torch.Tensor) else v)
     _lib.check(lib.mi_conv_forward(C.byref(d), stream()), "mi_conv_forward")
     torch.cuda.synchronize()
+    return lib.mi_debug_last_conv_route()        # 0 table-driven gather, 2 DMA shifted-run taps, 3 DMA row taps (include/demucs_amd.h)
 
 
 @pytest.mark.parametrize("Cout,Fr,T,pitch", [(96, 64, 48, 48), (128, 16, 336, 336), (48, 32, 61, 64), (192, 8, 37, 40)])
@@ -256,9 +259,10 @@ def test_float32_strided_frequency_conv_on_the_dma_row_route(lib, Cout, Fr, T, p
     outs = []
     for rows in (1, 0):
         y = torch.full((B, Cout, Fr // 4, pitch), float("nan"), device="cuda")
-        _conv_desc_call(lib, wt=wt, M=M, Mpad=Mpad, K=K, Kpad=Kpad, ktab=kt, x=xin, x_bstride=Cin * Fr * pitch, B=B, D1=Fr, D2=T, O1=Fr // 4,
-                        O2=pitch, S1=4, S2=1, row_mode=1, epi=EPI_LINEAR, flags=FLAG_GELU, bias=bias, y=y, y_bstride=Cout * P, y_cstride=P,
-                        tile_m=tile, o2_valid=T if pitch != T else 0, x_ld=pitch if pitch != T else 0, dma_rows=rows)
+        route = _conv_desc_call(lib, wt=wt, M=M, Mpad=Mpad, K=K, Kpad=Kpad, ktab=kt, x=xin, x_bstride=Cin * Fr * pitch, B=B, D1=Fr, D2=T,
+                                O1=Fr // 4, O2=pitch, S1=4, S2=1, row_mode=1, epi=EPI_LINEAR, flags=FLAG_GELU, bias=bias, y=y, y_bstride=Cout * P,
+                                y_cstride=P, tile_m=tile, o2_valid=T if pitch != T else 0, x_ld=pitch if pitch != T else 0, dma_rows=rows)
+        assert route == (3 if rows else 0)          # the two outputs really come from two main loops
         outs.append(y[..., :T].cpu())
     assert bool(torch.isfinite(outs[0]).all())
     assert maxerr(outs[0], want) < 2e-5
@@ -287,10 +291,11 @@ def test_float32_frequency_transposed_conv_on_the_dma_row_route(lib, Co, skip_on
     outs = []
     for rows in (1, 0):
         y = torch.full((B, Co, 4 * Fr, T), float("nan"), device="cuda")
-        _conv_desc_call(lib, wt=wt, M=M, Mpad=Mpad, K=K, Kpad=Kpad, ktab=kt, x=xin, x_bstride=Cc * Fr * T, B=B, D1=Fr, D2=T, O1=Fr + 1, O2=T,
-                        S1=1, S2=1, row_mode=1, epi=EPI_CONVTR, flags=FLAG_TR_FREQ | (FLAG_GELU | FLAG_RES if skip_on else 0),
-                        res=res if skip_on else 0, bias=bias, y=y, y_bstride=Co * 4 * Fr * T, y_cstride=4 * Fr * T, out_len=4 * Fr,
-                        tile_m=tile, dma_rows=rows)
+        route = _conv_desc_call(lib, wt=wt, M=M, Mpad=Mpad, K=K, Kpad=Kpad, ktab=kt, x=xin, x_bstride=Cc * Fr * T, B=B, D1=Fr, D2=T, O1=Fr + 1,
+                                O2=T, S1=1, S2=1, row_mode=1, epi=EPI_CONVTR, flags=FLAG_TR_FREQ | (FLAG_GELU | FLAG_RES if skip_on else 0),
+                                res=res if skip_on else 0, bias=bias, y=y, y_bstride=Co * 4 * Fr * T, y_cstride=4 * Fr * T, out_len=4 * Fr,
+                                tile_m=tile, dma_rows=rows)
+        assert route == (3 if rows else 0)
         outs.append(y.cpu())
     assert maxerr(outs[0], want) < 2e-5
     assert torch.equal(outs[0], outs[1])
@@ -327,8 +332,9 @@ def test_float32_pointwise_glu_layers_on_the_dma_row_route(lib, Cc, gn):
     outs = []
     for plain in (1, 0):
         y = torch.full((B, Cc, Fr, T), float("nan"), device="cuda")
-        _conv_desc_call(lib, wt=wt, M=M, Mpad=Mpad, K=K, Kpad=Kpad, ktab=kt, x=xin, x_bstride=K * P, B=B, D1=Fr, D2=T, O1=Fr, O2=T, S1=1, S2=1,
-                        row_mode=1, bias=bias, y=y, y_bstride=Cc * P, y_cstride=P, tile_m=tile, plain=plain, **extra)
+        route = _conv_desc_call(lib, wt=wt, M=M, Mpad=Mpad, K=K, Kpad=Kpad, ktab=kt, x=xin, x_bstride=K * P, B=B, D1=Fr, D2=T, O1=Fr, O2=T, S1=1,
+                                S2=1, row_mode=1, bias=bias, y=y, y_bstride=Cc * P, y_cstride=P, tile_m=tile, plain=plain, **extra)
+        assert route == (3 if plain else 0)
         outs.append(y.cpu())
     assert maxerr(outs[0], want) < (1e-4 if gn else 2e-5)
     assert torch.equal(outs[0], outs[1])
