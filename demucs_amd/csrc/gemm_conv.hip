@@ -247,7 +247,11 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_dma_kernel(const mi_conv_des
 // lane and K step.  Taps whose input ROW lies outside the frame read the zero page.  K2 = 3 (|d2| <= 1).
 // Tiles: 128 x 128 (2 x 2 waves) and 96 x 128 (1 x 4 waves; the A image [16][96] is six 1-KiB transfers: waves 0, 1 issue two
 // of them, waves 2, 3 one, so the counted waits are per wave).  Same 3-stage ring, one raw s_barrier per K step.
-template <int BMT, int EPI, int NT>
+// DIL (round 4, later): step between the K2 = 3 taps of a k = 3 conv -- the DConv blocks' dilated convs C -> C / 8 (demucs.py:138: dilation
+// 1 / 2, padding = dilation) with the row-statistics epilogue, on 32- and 64-row tiles (M = 24 / 48: two / four A transfers per K step).
+// With DIL > 1 up to DIL samples at either end of a row come from outside it: the lanes that own the first chunk of a row and the
+// chunks within eight columns of its valid end re-test their four elements per tap (a rare branch) instead of the single fix_l / fix_r.
+template <int BMT, int EPI, int NT, int DIL = 1>
 __global__ __launch_bounds__(256, 3) void conv_gemm_dmatap_kernel(const mi_conv_desc d, const int N, const int MT, const int Gm) {
     constexpr int BM = BMT, WM = BM == 128 ? 2 : 1, WN = 4 / WM, TM = BM / (32 * WM), TN = BN / (32 * WN);
     constexpr int SS = BK * (BM + BN);                       // floats per stage: A image then B image
@@ -268,13 +272,14 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_dmatap_kernel(const mi_conv_
     // ---- A: this wave's transfers of every K step ------------------------------------------------------------------------------
     // BM = 128: two transfers of two 128-float rows each (rows 4 wave + 2 j + (lane >> 5)); BM = 96: transfer q moves floats
     // [256 q, 256 q + 256) of the [16][96] image, q = wave and, for waves 0 and 1, q = 4 + wave
-    constexpr int NA = BM == 128 ? 2 : 2;                    // slots (the second one of waves 2, 3 is idle at BM = 96)
-    const bool a2 = BM == 128 || wave < 2;
+    // BM = 64: transfer q = wave (one each); BM = 32: two transfers in all, waves 0 and 1
+    constexpr int NA = BM >= 96 ? 2 : 1;                     // slots (the second one of waves 2, 3 is idle at BM = 96)
+    const bool a1 = BM != 32 || wave < 2, a2 = BM == 128 || (BM == 96 && wave < 2);
     int a_row[NA], a_col[NA], a_lds[NA];
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
         if (BM == 128) { a_row[j] = 4 * wave + 2 * j + (lane >> 5); a_col[j] = (lane & 31) * 4; a_lds[j] = (4 * wave + 2 * j) * BM; }
-        else { const int q = j ? 4 + wave : wave, f = 256 * q + 4 * lane; a_row[j] = f / 96; a_col[j] = f % 96; a_lds[j] = 256 * q; }
+        else { const int q = j ? 4 + wave : wave, f = 256 * q + 4 * lane; a_row[j] = f / BM; a_col[j] = f % BM; a_lds[j] = 256 * q; }
     }
     // ---- B: rows 4 wave + 2 j + (lane >> 5), 16 bytes at column 4 (lane & 31) ---------------------------------------------------
     const int c4 = (lane & 31) * 4, rb0 = 4 * wave + (lane >> 5);
@@ -284,12 +289,13 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_dmatap_kernel(const mi_conv_
     const int fix_l = (lc.valid && lc.o2 == 0) ? 0 : -1;
     const int fr = d.D2 - 1 - lc.o2;
     const int fix_r = (lc.valid && fr >= 0 && fr < 4) ? fr : -1;
+    const bool edge = lc.valid && (lc.o2 < 4 || lc.o2 + 8 > d.D2);       // DIL > 1: chunks that can hold an element from outside [0, D2)
 
 #define MI_TAPDMA_TILE(kt, stage)                                                                                   \
     do {                                                                                                            \
         float *sa = smem + (stage) * SS, *sb = sa + BK * BM + (4 * wave) * BN;                                      \
         _Pragma("unroll") for (int j = 0; j < NA; ++j)                                                              \
-            if (j == 0 || a2) {                                                                                     \
+            if (j == 0 ? a1 : a2) {                                                                                 \
                 const float *ga = d.wt + (size_t)((kt) * BK + a_row[j]) * d.Mpad + m0 + a_col[j];                   \
                 __builtin_amdgcn_global_load_lds((gvoid_t *)ga, (lvoid_t *)(sa + a_lds[j]), 16, 0, 0);              \
             }                                                                                                       \
@@ -297,7 +303,7 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_dmatap_kernel(const mi_conv_
             const int k = (kt) * BK + rb0 + 2 * j, ci = k / NT, tap = k - ci * NT, t1 = tap / K2, t2 = tap - t1 * K2; \
             const int i1 = lc.o1 + t1 - d.tap_pad1;                                                                 \
             const bool ok = lc.valid && k < d.K && (unsigned)i1 < (unsigned)d.D1;                                   \
-            const float *gb = xcol + (int64_t)ci * chan + (int64_t)(t1 - d.tap_pad1) * x_ld + (t2 - d.tap_pad2);    \
+            const float *gb = xcol + (int64_t)ci * chan + (int64_t)(t1 - d.tap_pad1) * x_ld + (t2 * DIL - d.tap_pad2); \
             __builtin_amdgcn_global_load_lds((gvoid_t *)(ok ? gb : zero), (lvoid_t *)(sb + 2 * j * BN), 16, 0, 0);  \
         }                                                                                                           \
     } while (0)
@@ -316,18 +322,29 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_dmatap_kernel(const mi_conv_
     if (nk > 1) MI_TAPDMA_TILE(1, 1);
     int stage = 0;
     for (int kt = 0; kt < nk; ++kt) {
-        // tile kt has landed once all but this wave's newest tile (4 transfers; 3 for waves 2, 3 of the 96-row tile) are done
+        // tile kt has landed once all but this wave's newest tile (2 B transfers + its A transfers: 4, 3 or 2) are done
         if (kt + 1 < nk) {
             if (a2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else if (a1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         {   // the conv's zero padding at the ends of the input rows, in the rows this lane transferred
             float *sb = smem + stage * SS + BK * BM + (4 * wave) * BN + (lane >> 5) * BN + c4;
+            if constexpr (DIL == 1) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int k = kt * BK + rb0 + 2 * j, tap = k % NT, dd2 = tap % K2 - d.tap_pad2;
-                if (dd2 < 0 && fix_l >= 0) sb[2 * j * BN + fix_l] = 0.f;
-                if (dd2 > 0 && fix_r >= 0) sb[2 * j * BN + fix_r] = 0.f;
+                for (int j = 0; j < 2; ++j) {
+                    const int k = kt * BK + rb0 + 2 * j, tap = k % NT, dd2 = tap % K2 - d.tap_pad2;
+                    if (dd2 < 0 && fix_l >= 0) sb[2 * j * BN + fix_l] = 0.f;
+                    if (dd2 > 0 && fix_r >= 0) sb[2 * j * BN + fix_r] = 0.f;
+                }
+            } else if (edge) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int k = kt * BK + rb0 + 2 * j, tap = k % NT, dd2 = (tap % K2) * DIL - d.tap_pad2;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if ((unsigned)(lc.o2 + e + dd2) >= (unsigned)d.D2) sb[2 * j * BN + e] = 0.f;
+                }
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -371,8 +388,14 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_dmatap_kernel(const mi_conv_
 static bool dmatap_eligible(const mi_conv_desc &d, int tile) {
     static const bool off = getenv("MI_NO_DMA_TAP") != nullptr;
     const int ld = d.x_ld ? d.x_ld : d.D2;
-    return !off && !d.half && !d.wx && d.epi == MI_EPI_GLU && (tile == 96 || tile == 128) && (d.ntaps == 9 || d.ntaps == 3) && d.tap_k2 == 3 &&
-           d.K % d.ntaps == 0 && d.S1 == 1 && d.S2 == 1 && d.O1 == d.D1 && d.O2 == ld && ld % 4 == 0 && d.tap_pad2 == 1 &&
+    static const bool off_dconv = getenv("MI_NO_DMA_DCONV") != nullptr;      // A/B switch for the BIAS_STATS kind alone
+    if (off_dconv && d.epi == MI_EPI_BIAS_STATS) return false;
+    const int dil = d.tap_dil2 ? d.tap_dil2 : 1;
+    // GLU: the decoders' 3 x 3 / k = 3 rewrite convs (96- / 128-row tiles); BIAS_STATS: the DConv blocks' dilated k = 3 convs (32- / 64-row)
+    const bool kind = (d.epi == MI_EPI_GLU && (tile == 96 || tile == 128) && (d.ntaps == 9 || d.ntaps == 3) && dil == 1) ||
+                      (d.epi == MI_EPI_BIAS_STATS && (tile == 32 || tile == 64) && d.ntaps == 3 && (dil == 1 || dil == 2) && d.flags == 0);
+    return !off && !d.half && !d.wx && kind && d.tap_k2 == 3 && d.Mpad % tile == 0 &&
+           d.K % d.ntaps == 0 && d.S1 == 1 && d.S2 == 1 && d.O1 == d.D1 && d.O2 == ld && ld % 4 == 0 && d.tap_pad2 == dil &&
            d.tap_pad1 == (d.ntaps / 3 - 1) / 2 && !(d.flags & (MI_FLAG_IMG | MI_FLAG_IMG4)) && d.x_bstride == (int64_t)(d.K / d.ntaps) * d.D1 * ld;
 }
 template <int EPI>
@@ -382,7 +405,13 @@ static int launch_dmatap(const mi_conv_desc &d, int tile, hipStream_t st) {
     const int N = (int)N64, MT = d.Mpad / tile, NT = ceil_div(N, BN);
     const unsigned grid = grouped_grid(MT, NT, 1);
     g_last_conv_route = 2;
-    if (tile == 128 && d.ntaps == 9) hipLaunchKernelGGL((conv_gemm_dmatap_kernel<128, EPI, 9>), dim3(grid), dim3(256), 0, st, d, N, MT, 1);
+    if constexpr (EPI == MI_EPI_BIAS_STATS) {
+        const bool d2 = d.tap_dil2 == 2;
+        if (tile == 64 && d2) hipLaunchKernelGGL((conv_gemm_dmatap_kernel<64, EPI, 3, 2>), dim3(grid), dim3(256), 0, st, d, N, MT, 1);
+        else if (tile == 64) hipLaunchKernelGGL((conv_gemm_dmatap_kernel<64, EPI, 3, 1>), dim3(grid), dim3(256), 0, st, d, N, MT, 1);
+        else if (d2) hipLaunchKernelGGL((conv_gemm_dmatap_kernel<32, EPI, 3, 2>), dim3(grid), dim3(256), 0, st, d, N, MT, 1);
+        else hipLaunchKernelGGL((conv_gemm_dmatap_kernel<32, EPI, 3, 1>), dim3(grid), dim3(256), 0, st, d, N, MT, 1);
+    } else if (tile == 128 && d.ntaps == 9) hipLaunchKernelGGL((conv_gemm_dmatap_kernel<128, EPI, 9>), dim3(grid), dim3(256), 0, st, d, N, MT, 1);
     else if (tile == 128) hipLaunchKernelGGL((conv_gemm_dmatap_kernel<128, EPI, 3>), dim3(grid), dim3(256), 0, st, d, N, MT, 1);
     else if (d.ntaps == 9) hipLaunchKernelGGL((conv_gemm_dmatap_kernel<96, EPI, 9>), dim3(grid), dim3(256), 0, st, d, N, MT, 1);
     else hipLaunchKernelGGL((conv_gemm_dmatap_kernel<96, EPI, 3>), dim3(grid), dim3(256), 0, st, d, N, MT, 1);
@@ -749,7 +778,8 @@ int launch_conv(const mi_conv_desc &din, hipStream_t st) {
     if (small_tile && !plain && d.epi == MI_EPI_GLU && tile == 128 && d.Mpad % 96 == 0 &&
         (int64_t)(d.Mpad / 128) * ceil_div((int64_t)d.B * d.O1 * d.O2, BN) < 200)
         ktile = 96;
-    if (!plain && dmatap_eligible(d, ktile)) return launch_dmatap<MI_EPI_GLU>(d, ktile, st);
+    if (!plain && dmatap_eligible(d, ktile))
+        return d.epi == MI_EPI_GLU ? launch_dmatap<MI_EPI_GLU>(d, ktile, st) : launch_dmatap<MI_EPI_BIAS_STATS>(d, ktile, st);
     if (dmarow_eligible(d, tile, plain)) {
         switch (d.epi) {
             case MI_EPI_LINEAR: return launch_dmarow<MI_EPI_LINEAR, MI_FLAG_GELU>(d, tile, st);

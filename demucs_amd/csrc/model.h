@@ -163,6 +163,7 @@ struct Model : WorkspacePtrs {
     int load_dconv(const WeightTable &wt, const std::string &prefix, int C, int64_t chan_stride, int D2, bool freq, DConvW *dw, int comp = 8);
     int alloc_workspace();
     int fill_workspace(Workspace &w);
+    bool dconv_tap_dma = false;  // run_dconv may state the k = 3 convs' geometry (DMA tap route): only when x / tmp carry 128 bytes of slack
     int run_dconv(const DConvW &w, int C, const Geo &g, float *x, float *tmp, float *hidden, double *stats, float2 *st1, float2 *st2,
                   hipStream_t st, double *gram2 = nullptr, size_t gram2_cap = 0);
     int run_tr_layer(int br, int k, int B, const float *x, const float2 *xstat, const float *other, const float2 *ostat, float *out,

@@ -623,6 +623,7 @@ int Model::alloc_workspace() {
         ws = w;
     }
     static_cast<WorkspacePtrs &>(*this) = *ws;
+    dconv_tap_dma = true;        // fill_workspace gave w_a / w_b / w_ta / w_tb the slack the shifted DMA runs need
     return MI_OK;
 }
 
@@ -649,12 +650,14 @@ int Model::fill_workspace(Workspace &w) {
             w.w_eimg[0][i] = pf; w.w_eimg[1][i] = pt;
         }
     // scratch shared by all U-Net layers (largest layer: 48 x 512 x T)
-    MI_TRY(A(&w.w_a, big)); MI_TRY(A(&w.w_b, big)); MI_TRY(A(&w.w_h, big / 2));
-    MI_TRY(A(&w.w_ta, big)); MI_TRY(A(&w.w_tb, big)); MI_TRY(A(&w.w_th, big / 2));
-    // the decoder inputs: the float32 k x k convs read them by LDS-DMA in runs shifted by one sample (gemm_conv.hip
-    // conv_gemm_dmatap_kernel), i.e. up to 4 bytes before the first and 12 after the last element: 128 bytes of slack on both sides
-    MI_TRY(w.alloc((void **)&w.w_c, (big * B + 64) * sizeof(float))); w.w_c += 32;
-    MI_TRY(w.alloc((void **)&w.w_tc, (big * B + 64) * sizeof(float))); w.w_tc += 32;
+    MI_TRY(A(&w.w_h, big / 2)); MI_TRY(A(&w.w_th, big / 2));
+    // the decoder inputs and the DConv blocks' input / output pair: the float32 k x k convs read them by LDS-DMA in runs shifted by
+    // one or two samples (gemm_conv.hip conv_gemm_dmatap_kernel), i.e. up to 8 bytes before the first and 20 after the last
+    // element: 128 bytes of slack on both sides
+    for (float **p : {&w.w_a, &w.w_b, &w.w_ta, &w.w_tb, &w.w_c, &w.w_tc}) {
+        MI_TRY(w.alloc((void **)p, (big * B + 64) * sizeof(float)));
+        *p += 32;
+    }
     // DConv hidden tensors carry round_up(C/8, 16) channels; the padding channels must read as zero
     MI_HIP(hipMemset(w.w_h, 0, (big / 2) * B * sizeof(float)));
     MI_HIP(hipMemset(w.w_th, 0, (big / 2) * B * sizeof(float)));
@@ -760,6 +763,9 @@ int Model::run_dconv(const DConvW &w, int C, const Geo &g, float *x, float *tmp,
         const DConvLayerW &l = w.l[dlayer];
         mi_conv_desc d = base_desc(l.conv3, l.ktab3, src, (int64_t)C * P, g);
         d.epi = MI_EPI_BIAS_STATS; d.y = hidden; d.y_bstride = (int64_t)hp * P; d.y_cstride = P; d.stats = stats;
+        if (dconv_tap_dma) {     // the conv's geometry (k = 3, dilation 2^dlayer = padding): float32 runs it on the DMA tap loop; x / tmp carry slack
+            d.ntaps = 3; d.tap_k2 = 3; d.tap_pad1 = 0; d.tap_pad2 = 1 << dlayer; d.tap_dil2 = 1 << dlayer;
+        }
         MI_TRY(conv(d, st));
         MI_TRY(launch_finalize_stats(stats, rows, cnt_row * h, 1e-5f, 0, st1, nullptr, st));
         // GroupNorm + GELU of the hidden tensor in place, and in the same pass the Gram sums from which the second GroupNorm's

@@ -340,6 +340,46 @@ def test_float32_pointwise_glu_layers_on_the_dma_row_route(lib, Cc, gn):
     assert torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("h,dil,Fr,T,pitch", [(24, 1, 6, 336, 336), (24, 2, 5, 61, 64), (48, 2, 3, 140, 140), (48, 1, 1, 21499, 21500)])
+def test_float32_dilated_k3_conv_with_row_statistics_on_the_dma_tap_route(lib, h, dil, Fr, T, pitch):
+    """The DConv blocks' first conv (demucs.py:138: Conv1d C -> C / 8, k = 3, dilation = padding = 1 / 2) with the row-statistics
+    epilogue, on the 32- / 64-row tiles of the DMA tap loop (conv_gemm_dmatap_kernel<.., BIAS_STATS, 3, DIL>): shifted runs, up to
+    two samples from outside the row at either end re-zeroed in LDS.  Frequency-branch rows (b, fr) and a time-branch row with a
+    pitch wider than its valid length (NaN in the padding).  Float64 reference, bit identity of the stored tensor with the
+    table-driven gather, statistics to 1e-9 relative (float64 atomics: summation order differs between launches)."""
+    B, Cc = 2, 8 * h
+    x, W, b = rnd(B, Cc, Fr, T, seed=61), rnd(h, Cc, 1, 3, seed=62, scale=0.1), rnd(h, seed=63)
+    want = F.conv2d(x, W, b, padding=(0, dil), dilation=(1, dil))
+    wt, bias, M, Mpad, K, Kpad, tile = pack_w(W.reshape(h, -1), b)
+    assert tile in (32, 64)
+    P = Fr * pitch
+    xp = torch.full((B, Cc, Fr, pitch), float("nan"))
+    xp[..., :T] = x.float()
+    buf = torch.full((B * Cc * P + 64,), float("nan"), device="cuda")       # 32 floats of slack on both sides, as the engine's buffers carry
+    buf[32:32 + B * Cc * P] = xp.reshape(-1).cuda()
+    xin = buf[32:32 + B * Cc * P]
+    kt = ktab(Cc, 1, 3, 1, dil, 0, dil, P, pitch, Kpad)
+    row_mode, nrows = (1, B * Fr) if Fr > 1 else (0, B)
+    outs, sts = [], []
+    for geo in (dict(ntaps=3, tap_k2=3, tap_pad1=0, tap_pad2=dil, tap_dil2=dil), {}):
+        y = torch.full((B, h, Fr, pitch), float("nan"), device="cuda")
+        stats = torch.zeros(nrows, SLOTS, 2, dtype=torch.float64, device="cuda")
+        route = _conv_desc_call(lib, wt=wt, M=M, Mpad=Mpad, K=K, Kpad=Kpad, ktab=kt, x=xin, x_bstride=Cc * P, B=B, D1=Fr, D2=T, O1=Fr, O2=pitch,
+                                S1=1, S2=1, row_mode=row_mode, epi=EPI_BIAS_STATS, bias=bias, y=y, y_bstride=h * P, y_cstride=P, stats=stats,
+                                tile_m=tile, o2_valid=T if pitch != T else 0, x_ld=pitch if pitch != T else 0, **geo)
+        assert route == (2 if geo else 0)
+        outs.append(y[..., :T].cpu())
+        sts.append(stats.sum(1).cpu())
+    assert bool(torch.isfinite(outs[0]).all())
+    assert maxerr(outs[0], want) < 6e-6 * float(want.abs().max())          # K = 576 / 1 152 float32 products, outputs up to ~8
+    assert torch.equal(outs[0], outs[1])
+    rows = want.permute(0, 2, 1, 3).reshape(nrows, -1) if row_mode else want.reshape(B, -1)
+    ref = torch.stack([rows.sum(1), (rows ** 2).sum(1)], 1)
+    for st in sts:
+        assert ((st - ref).abs() / ref.abs().clamp_min(1.0)).max().item() < 2e-5        # float32 values, float32 per-thread partial sums
+    assert ((sts[0] - sts[1]).abs() / sts[1].abs().clamp_min(1.0)).max().item() < 1e-9
+
+
 def test_linear_scale_residual_big_k(lib, x6):
     """nn.Linear on channel-first tokens with LayerScale + residual epilogue (transformer.py:364-367):
     M=512, K=2048 exercises the 128-row tile and a long contraction."""
