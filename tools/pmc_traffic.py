@@ -31,7 +31,7 @@ def klass(name):
     m = re.search(r"conv_gemm_dma_kernel<(\d+), (\d+)>", name)      # LDS-DMA main loop of the plain 128-row LINEAR tile
     if m:
         return f"conv_gemm<{EPI[int(m.group(1))]},tile128,1x1>"
-    m = re.search(r"conv_gemm_dmatap_kernel<(\d+), (\d+), (\d+)>", name)      # round 4: LDS-DMA main loop of the float32 k x k GLU convs
+    m = re.search(r"conv_gemm_dmatap_kernel<(\d+), (\d+), (\d+)(?:, \d+)?>", name)      # round 4: LDS-DMA main loop of the float32 k x k GLU convs
     if m:
         return f"conv_gemm<{EPI[int(m.group(2))]},tile{m.group(1)}>"
     m = re.search(r"conv_gemm_dmarow_kernel<(\d+), (\d+), (\d+)>", name)      # round 4: LDS-DMA main loop of the float32 row-tap layers
