@@ -19,7 +19,11 @@ constexpr int HD = 64;       // head dim
 constexpr int KT = 64;       // keys per LDS tile
 constexpr int VLD = KT + 1;  // V tile row stride (A-operand reads walk rows: odd stride = no bank conflicts)
 
-__global__ __launch_bounds__(256) void attention_kernel(const float *__restrict__ q, const float *__restrict__ k,
+// Three workgroups per CU (round 4): without the bound hipcc took 192 VGPRs = two waves per SIMD; at 168 the five values it spills are
+// written before the key loop and read after it (ISA checked), and the third wave per SIMD hides more of each wave's
+// MFMA -> softmax -> MFMA chain: 119.5 -> 123.5 TFLOP/s, fp32 step 102.1 -> 101.0 ms (alternating runs).  Four (128 VGPRs) spills 70
+// values inside the loop.
+__global__ __launch_bounds__(256, 3) void attention_kernel(const float *__restrict__ q, const float *__restrict__ k,
                                                         const float *__restrict__ v, float *__restrict__ o, int Tq, int Tk,
                                                         int64_t q_bs, int64_t kv_bs, int64_t o_bs, int planes, int heads) {
     __shared__ float Ks[HD][KT];
