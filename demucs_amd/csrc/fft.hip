@@ -287,8 +287,8 @@ __global__ __launch_bounds__(256) void istft_ola_kernel(const float *__restrict_
 // item) are never written or re-read: 2.7 GB of the 4.8 GB the two separate kernels move per batched forward; the price is three
 // warm-up frames per run (the blocks they complete belong to the previous run).  The next frame's spectrum is fetched into
 // registers under the current frame's passes.
-// grid (runs, B*S), block 256; run g owns hop blocks [3 + g * R, 3 + (g + 1) * R)
-__global__ __launch_bounds__(256, 2) void istft_fused_kernel(const float *__restrict__ yt, int T, int L, int R, const float *__restrict__ window,
+// grid (runs, B*S), block 256; run g owns hop blocks [3 + g * R, 3 + (g + 1) * R).  Three workgroups per CU (137 VGPRs, 50 KB of LDS each).
+__global__ __launch_bounds__(256, 3) void istft_fused_kernel(const float *__restrict__ yt, int T, int L, int R, const float *__restrict__ window,
                                                           const float2 *__restrict__ tw, const float *__restrict__ env,
                                                           const float *__restrict__ xt, const float2 *__restrict__ denorm_t, int S,
                                                           int xt_pitch, float *__restrict__ out) {
@@ -313,28 +313,32 @@ __global__ __launch_bounds__(256, 2) void istft_fused_kernel(const float *__rest
     for (int m = m_first; m <= m_last; ++m) {
         const bool live = m >= 0 && m < T;                   // workgroup-uniform: frames outside the data are the zero pad
         if (live) {
+            // the thread index as the transform sees it is made opaque per frame: otherwise hipcc hoists the ~80 LDS offsets of the
+            // three passes out of the frame loop as invariants and the kernel needs 236 registers (two workgroups per CU)
+            int iv = i;
+            asm volatile("" : "+v"(iv));
             const float *src = yt + ((size_t)bs * T + m) * 4 * kBins;
             __syncthreads();                                 // the previous frame's last LDS reads are done (and the twiddles staged)
             // (two workgroups share a CU: the other one covers this frame's loads; a register prefetch of the next
             // frame cost 32 VGPRs and a spill at two workgroups per CU)
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
-                const int k = i + 256 * r;
+                const int k = iv + 256 * r;
                 float ar = src[k], ai = src[kBins + k], br = src[2 * kBins + k], bi = src[3 * kBins + k];
                 if (k == 0) { ai = 0.f; bi = 0.f; }
                 re[lpad(k)] = ar - bi; im[lpad(k)] = ai + br;
                 if (k > 0) { re[lpad(kN - k)] = ar + bi; im[lpad(kN - k)] = br - ai; }
             }
-            if (i == 0) { re[lpad(kBins)] = 0.f; im[lpad(kBins)] = 0.f; }
+            if (iv == 0) { re[lpad(kBins)] = 0.f; im[lpad(kBins)] = 0.f; }
             __syncthreads();
             cf u[16];
-            load_pass_input<true>(u, i, re, im);
+            load_pass_input<true>(u, iv, re, im);
             __syncthreads();
-            stockham_pass<true, 1>(u, i, re, im, twr, twi);
-            fft_tail<true>(u, i, re, im, twr, twi);
+            stockham_pass<true, 1>(u, iv, re, im, twr, twi);
+            fft_tail<true>(u, iv, re, im, twr, twi);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {                   // sample p = i + 256 r: segment r / 4, offset i + 256 (r % 4)
-                const int p = i + 256 * r;
+                const int p = iv + 256 * r;
                 const float w = window[p] * (1.0f / 64.0f);          // L1 / L2 hit: 16 KB shared by every workgroup
                 acc[r >> 2][r & 3][0] += re[lpad(p)] * w;
                 acc[r >> 2][r & 3][1] += im[lpad(p)] * w;
