@@ -34,14 +34,13 @@ static int get_tables(FftTables *out) {
     static Tables tb;
     if (!tb.ready) {
         std::vector<float> win(4096), env(1024);
-        std::vector<float2> tw(2048);
+        const std::vector<float2> tw = fft_twiddle_table();
         for (int i = 0; i < 4096; ++i) win[i] = 0.5f - 0.5f * cosf((float)i * (float)(2.0 * M_PI / 4096.0));
-        for (int i = 0; i < 2048; ++i) { const double a = -2.0 * M_PI * i / 4096.0; tw[i] = make_float2((float)cos(a), (float)sin(a)); }
         for (int r = 0; r < 1024; ++r) { float e = 0.f; for (int j = 3; j >= 0; --j) e += win[r + 1024 * j] * win[r + 1024 * j]; env[r] = e; }
         float *dw, *de; float2 *dt;
-        MI_HIP(hipMalloc((void **)&dw, 4096 * 4)); MI_HIP(hipMalloc((void **)&dt, 2048 * 8)); MI_HIP(hipMalloc((void **)&de, 1024 * 4));
+        MI_HIP(hipMalloc((void **)&dw, 4096 * 4)); MI_HIP(hipMalloc((void **)&dt, tw.size() * 8)); MI_HIP(hipMalloc((void **)&de, 1024 * 4));
         MI_HIP(hipMemcpy(dw, win.data(), 4096 * 4, hipMemcpyHostToDevice));
-        MI_HIP(hipMemcpy(dt, tw.data(), 2048 * 8, hipMemcpyHostToDevice));
+        MI_HIP(hipMemcpy(dt, tw.data(), tw.size() * 8, hipMemcpyHostToDevice));
         MI_HIP(hipMemcpy(de, env.data(), 1024 * 4, hipMemcpyHostToDevice));
         tb.t = FftTables{dw, dt, de};
         tb.ready = true;

@@ -19,16 +19,36 @@ constexpr int kBins = 2048;
 __device__ __forceinline__ int lpad(int i) { return i + (i >> 5); }   // LDS index padding (bank spread)
 constexpr int kLdsN = kN + kN / 32;
 
-struct cf { float x, y; };
-__device__ __forceinline__ cf operator+(cf a, cf b) { return {a.x + b.x, a.y + b.y}; }
-__device__ __forceinline__ cf operator-(cf a, cf b) { return {a.x - b.x, a.y - b.y}; }
-__device__ __forceinline__ cf cmul(cf a, cf b) { return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+// complex values as float32 pairs in adjacent registers: + and - are one v_pk_add_f32; a complex product is two v_pk_mul_f32 and
+// one v_pk_add_f32 (separate IEEE multiplies and adds, as before: nothing is contracted), the multiplication by +-i of the
+// radix-4 butterfly rides on the operand selectors of the add.  Written as inline asm: from C++ swizzles hipcc builds the same
+// values with v_mov / v_xor around the packed instructions.  The transforms are bound by VALU issue (tools/micro/README.md).
+typedef float cf __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ cf cmul(cf a, cf b) {
+    cf p1, p2, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(p1) : "v"(a), "v"(b));      // (ax bx, ax by)
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(p2) : "v"(a), "v"(b));      // (ay by, ay bx)
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(p1), "v"(p2));                     // (ax bx - ay by, ax by + ay bx)
+    return r;
+}
+// a + i b = (ax - by, ay + bx) and a - i b = (ax + by, ay - bx)
+__device__ __forceinline__ cf add_i(cf a, cf b) {
+    cf r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ cf sub_i(cf a, cf b) {
+    cf r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 
 template <bool INV>
 __device__ __forceinline__ void dft4(cf &a, cf &b, cf &c, cf &d) {
-    cf t0 = a + c, t1 = a - c, t2 = b + d, t3 = b - d;
-    cf jt3 = INV ? cf{-t3.y, t3.x} : cf{t3.y, -t3.x};   // (-i)*t3 forward, (+i)*t3 inverse
-    a = t0 + t2; c = t0 - t2; b = t1 + jt3; d = t1 - jt3;
+    const cf t0 = a + c, t1 = a - c, t2 = b + d, t3 = b - d;
+    a = t0 + t2; c = t0 - t2;
+    if (INV) { b = add_i(t1, t3); d = sub_i(t1, t3); }        // t1 +- (+i) t3
+    else { b = sub_i(t1, t3); d = add_i(t1, t3); }            // t1 +- (-i) t3
 }
 
 // in-register 16-point DFT; result X[k1 + 4*k2] is left in u[4*k1 + k2]
@@ -49,6 +69,10 @@ __device__ __forceinline__ void dft16(cf (&u)[16]) {
 
 // One Stockham pass: u[] already holds x[i + 256 r] (r = 0..15) of thread i; P = 1, 16 or 256.
 // Writes the pass output to LDS re/im (natural order after the P = 256 pass).
+// The twiddle half table sits in LDS with the same one-word-per-32 padding as the data (index lpad(h)): the passes read it at
+// strides 16 r (P = 16) and r (P = 256) words, which on the unpadded table put the 16 / 32 lanes of an access group on one to four
+// banks (8- to 16-way conflicts: SQ_LDS_BANK_CONFLICT was 56 % of the LDS cycles of the fused iSTFT); the padding spreads every
+// power-of-two stride over the 32 banks.
 template <bool INV, int P>
 __device__ __forceinline__ void stockham_pass(cf (&u)[16], int i, float *re, float *im, const float *twr, const float *twi) {
     const int k = i & (P - 1);
@@ -57,9 +81,9 @@ __device__ __forceinline__ void stockham_pass(cf (&u)[16], int i, float *re, flo
 #pragma unroll
         for (int r = 1; r < 16; ++r) {
             // half table: W[n + 2048] = -W[n]
-            const int n = step * r, h = n & (kN / 2 - 1);
+            const int n = step * r, h = lpad(n & (kN / 2 - 1));
             const float sg = (n & (kN / 2)) ? -1.f : 1.f;
-            cf w = {sg * twr[h], (INV ? -sg : sg) * twi[h]};
+            const cf w = {sg * twr[h], (INV ? -sg : sg) * twi[h]};
             u[r] = cmul(u[r], w);
         }
     }
@@ -99,14 +123,16 @@ __device__ __forceinline__ void fft_tail(cf (&u)[16], int i, float *re, float *i
     __syncthreads();
 }
 
+constexpr int kTwLds = kN / 2 + kN / 64;       // padded half table
 __device__ __forceinline__ void stage_twiddles(const float2 *tw, float *twr, float *twi, int i) {
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
         float2 w = tw[i + 256 * r];
-        twr[i + 256 * r] = w.x;
-        twi[i + 256 * r] = w.y;
+        twr[lpad(i + 256 * r)] = w.x;
+        twi[lpad(i + 256 * r)] = w.y;
     }
 }
+#define MI_FFT_LDS __shared__ float re[kLdsN], im[kLdsN], twr[kTwLds], twi[kTwLds]
 
 // ---------------------------------------------------------------------------------------------
 // STFT: grid (T, B), block 256.  mix (B,2,L) -> zt[b][t][4][2048] + per-item (sum, sumsq) in fp64.
@@ -114,7 +140,7 @@ __device__ __forceinline__ void stage_twiddles(const float2 *tw, float *twr, flo
 __global__ __launch_bounds__(256) void stft_frames_kernel(const float *__restrict__ mix, int L, int T, int el, int er,
                                                           const float *__restrict__ window, const float2 *__restrict__ tw,
                                                           float *__restrict__ zt, double *__restrict__ stats) {
-    __shared__ float re[kLdsN], im[kLdsN], twr[kN / 2], twi[kN / 2];
+    MI_FFT_LDS;
     __shared__ double red[8];
     const int i = threadIdx.x, t = blockIdx.x, b = blockIdx.y;
     stage_twiddles(tw, twr, twi, i);
@@ -221,7 +247,7 @@ __global__ __launch_bounds__(256) void spec_transpose_kernel(const float *__rest
 // grid (T, B*S), block 256
 __global__ __launch_bounds__(256) void istft_frames_kernel(const float *__restrict__ yt, int T, const float *__restrict__ window,
                                                            const float2 *__restrict__ tw, float *__restrict__ fr) {
-    __shared__ float re[kLdsN], im[kLdsN], twr[kN / 2], twi[kN / 2];
+    MI_FFT_LDS;
     const int i = threadIdx.x, t = blockIdx.x, bs = blockIdx.y;
     stage_twiddles(tw, twr, twi, i);
     const float *src = yt + ((size_t)bs * T + t) * 4 * kBins;
@@ -287,12 +313,12 @@ __global__ __launch_bounds__(256) void istft_ola_kernel(const float *__restrict_
 // item) are never written or re-read: 2.7 GB of the 4.8 GB the two separate kernels move per batched forward; the price is three
 // warm-up frames per run (the blocks they complete belong to the previous run).  The next frame's spectrum is fetched into
 // registers under the current frame's passes.
-// grid (runs, B*S), block 256; run g owns hop blocks [3 + g * R, 3 + (g + 1) * R).  Three workgroups per CU (137 VGPRs, 50 KB of LDS each).
+// grid (runs, B*S), block 256; run g owns hop blocks [3 + g * R, 3 + (g + 1) * R).  Three workgroups per CU (117 VGPRs, 50.8 KB of LDS each).
 __global__ __launch_bounds__(256, 3) void istft_fused_kernel(const float *__restrict__ yt, int T, int L, int R, const float *__restrict__ window,
                                                           const float2 *__restrict__ tw, const float *__restrict__ env,
                                                           const float *__restrict__ xt, const float2 *__restrict__ denorm_t, int S,
                                                           int xt_pitch, float *__restrict__ out) {
-    __shared__ float re[kLdsN], im[kLdsN], twr[kN / 2], twi[kN / 2];
+    MI_FFT_LDS;
     const int i = threadIdx.x, bs = blockIdx.y;
     const int hb0 = 3 + blockIdx.x * R, hb_last = (L - 1 + 3584) >> 10;        // first block of this run, last block of the signal
     const int hb1 = min(hb0 + R, hb_last + 1);

@@ -1,5 +1,7 @@
 // Internal launcher declarations shared by the engine's translation units.
 #pragma once
+#include <cmath>
+#include <vector>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -9,9 +11,16 @@ namespace mi {
 
 struct FftTables {
     const float *window;    // [4096] periodic Hann, float32 like th.hann_window
-    const float2 *twiddle;  // [2048] exp(-2 pi i n / 4096)
+    const float2 *twiddle;  // [2048] fft_twiddle_table(): exp(-2 pi i n / 4096)
     const float *envelope;  // [1024] sum_j window^2[r + 1024 j]
 };
+// W^n = exp(-2 pi i n / 4096) for n < 2048 (W^(n + 2048) = -W^n), float32 of the float64 value: one builder for both engines and the
+// handle-free entry points
+static inline std::vector<float2> fft_twiddle_table() {
+    std::vector<float2> tw(2048);
+    for (int i = 0; i < 2048; ++i) { const double a = -2.0 * M_PI * i / 4096.0; tw[i] = make_float2((float)cos(a), (float)sin(a)); }
+    return tw;
+}
 
 // fft.hip
 int launch_stft_frames(const float *mix, int B, int L, const FftTables &tb, float *zt, double *stats, hipStream_t st);

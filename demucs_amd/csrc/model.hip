@@ -415,12 +415,8 @@ int Model::init(const mi_config &c, const mi_tensor_desc *weights, size_t n) {
     // ---- FFT tables (window in float32 arithmetic like th.hann_window, spec.py:19,41) ------------
     {
         std::vector<float> win(4096), env(1024);
-        std::vector<float2> tw(2048);
+        const std::vector<float2> tw = fft_twiddle_table();
         for (int i = 0; i < 4096; ++i) win[i] = 0.5f - 0.5f * cosf((float)i * (float)(2.0 * M_PI / 4096.0));
-        for (int i = 0; i < 2048; ++i) {
-            const double a = -2.0 * M_PI * i / 4096.0;
-            tw[i] = make_float2((float)cos(a), (float)sin(a));
-        }
         for (int r = 0; r < 1024; ++r) {
             float e = 0.f;
             for (int j = 3; j >= 0; --j) e += win[r + 1024 * j] * win[r + 1024 * j];   // ascending frame order
