@@ -30,6 +30,13 @@ __device__ __forceinline__ void wave_sum2(double &a, double &b) {
 __device__ __forceinline__ float2 ld2(const float *p, bool ok) {
     return ok ? *reinterpret_cast<const float2 *>(p) : make_float2(0.f, 0.f);
 }
+// the value lane - 1 / lane + 1 holds in the same register (0 for lane 0 / lane 63): one v_mov_b32_dpp, no LDS
+__device__ __forceinline__ float dpp_from_lower(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138 /* wave_shr:1 */, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float dpp_from_upper(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130 /* wave_shl:1 */, 0xf, 0xf, true));
+}
 
 constexpr int kGramGroup = 16;      // Gram entries reduced per LDS round
 
@@ -76,21 +83,23 @@ __device__ __forceinline__ void dconv_row_layer(const DConvTimeLayer &LT, const 
     for (int j = 0; j < kNC; ++j)
 #pragma unroll
         for (int m = 0; m < HA / 2; ++m) hid[j][m] = (v2f){smalls[2 * m], smalls[2 * m + 1]};
-    const bool has_l = on && t0 >= 2, has_r = on && t0 + kNC + 2 <= T;
-    // taps of channels c + 1 AND c + 2 are in flight under the products of channel c: with two or three waves per SIMD one
-    // channel ahead (72 packed FMAs ~ 0.15 us) does not cover an L2 / HBM round trip (SQ_WAIT_ANY was 40 % of the wave cycles)
-    float2 n0 = ld2(src + t0 - 2, has_l), n1 = ld2(src + t0, on), n2 = ld2(src + t0 + 2, on), n3 = ld2(src + t0 + 4, on),
-           n4 = ld2(src + t0 + 6, has_r);
-    float2 m0 = ld2(src + cs + t0 - 2, has_l), m1 = ld2(src + cs + t0, on), m2 = ld2(src + cs + t0 + 2, on), m3 = ld2(src + cs + t0 + 4, on),
-           m4 = ld2(src + cs + t0 + 6, has_r);
+    // A lane fetches only its OWN six columns of a channel (three aligned float2); the two columns on either side that the taps
+    // reach come from the neighbouring lanes' registers by DPP wave shifts (v_mov_b32_dpp wave_shr / wave_shl, zero for the lanes
+    // without a neighbour = the conv's zero padding at the row ends; lanes past the row hold zeros).  Round 3 loaded all ten
+    // columns per lane: 40 instead of 24 bytes per lane and channel through L1 / L2, two thirds more than the row holds.
+    // Channels c + 1 .. c + 3 are in flight under the products of channel c (six registers per channel instead of ten).
+    float2 a1 = ld2(src + t0, on), a2 = ld2(src + t0 + 2, on), a3 = ld2(src + t0 + 4, on);
+    float2 b1 = ld2(src + cs + t0, on), b2 = ld2(src + cs + t0 + 2, on), b3 = ld2(src + cs + t0 + 4, on);
+    float2 e1 = ld2(src + 2 * cs + t0, on && C > 2), e2 = ld2(src + 2 * cs + t0 + 2, on && C > 2), e3 = ld2(src + 2 * cs + t0 + 4, on && C > 2);
 #pragma unroll UNR
     for (int c = 0; c < C; ++c) {
-        const v2f v[10] = {splat2(n0.x), splat2(n0.y), splat2(n1.x), splat2(n1.y), splat2(n2.x), splat2(n2.y), splat2(n3.x), splat2(n3.y),
-                           splat2(n4.x), splat2(n4.y)};
-        n0 = m0; n1 = m1; n2 = m2; n3 = m3; n4 = m4;
-        if (c + 2 < C) {
-            const float *p = src + (c + 2) * cs + t0;
-            m0 = ld2(p - 2, has_l); m1 = ld2(p, on); m2 = ld2(p + 2, on); m3 = ld2(p + 4, on); m4 = ld2(p + 6, has_r);
+        const float l0 = dpp_from_lower(a3.x), l1 = dpp_from_lower(a3.y), r0 = dpp_from_upper(a1.x), r1 = dpp_from_upper(a1.y);
+        const v2f v[10] = {splat2(l0), splat2(l1), splat2(a1.x), splat2(a1.y), splat2(a2.x), splat2(a2.y), splat2(a3.x), splat2(a3.y),
+                           splat2(r0), splat2(r1)};
+        a1 = b1; a2 = b2; a3 = b3; b1 = e1; b2 = e2; b3 = e3;
+        if (c + 3 < C) {
+            const float *p = src + (c + 3) * cs + t0;
+            e1 = ld2(p, on); e2 = ld2(p + 2, on); e3 = ld2(p + 4, on);
         }
         const float4 *wv = reinterpret_cast<const float4 *>(w0s + c * 3 * HA);
 #pragma unroll
