@@ -65,7 +65,9 @@ int launch_pack_tap(const float *wt, int Mpad, int Cin, int ntaps, int dtype, vo
 }
 
 template <int HT, int WM, int WN, int TM, int TN, int EPI, int LFLAGS>
-__global__ __launch_bounds__(256, 2) void conv_gemm_half_tap_kernel(const mi_conv_desc d, const int N, const int MT, const int Gm) {
+// Three workgroups per CU (round 4: the bound was 2 and hipcc took 192-196 registers for the 128-row tiles; at 168 nothing goes to
+// scratch): the 128-row GLU class 4.33 -> 3.80 ms and the transposed convs 3.17 -> 2.77 ms per three steps, bf16 step -0.3 ms.
+__global__ __launch_bounds__(256, 3) void conv_gemm_half_tap_kernel(const mi_conv_desc d, const int N, const int MT, const int Gm) {
     constexpr int BM = WM * TM * 32, AP = 128;                  // A rows per octet in LDS (padded: two DMA instructions per octet)
     static_assert(WN * TN * 32 == BN && WM * WN == 4 && BM <= AP, "4 waves, 128 columns, at most 128 rows");
     constexpr int SW = 4 * AP + 4 * BN;                          // 16-byte words per stage (16 KiB)
