@@ -67,7 +67,9 @@ int launch_pack_half(const float *wt, int Kpad, int Mpad, int dtype, void *wh, h
 }
 
 template <int HT, int WM, int WN, int TM, int TN, int EPI, int LFLAGS, bool PLAIN>
-__global__ __launch_bounds__(256, 2) void conv_gemm_half_kernel(const mi_conv_desc d, const int N, const int MT, const int Gm) {
+// tiles of up to 96 rows: three workgroups per CU (their accumulators leave room: <= 168 registers with nothing in scratch; the 128- and
+// 256-row variants would spill up to 557 values at that bound)
+__global__ __launch_bounds__(256, (WM * TM * TN <= 3 ? 3 : 2)) void conv_gemm_half_kernel(const mi_conv_desc d, const int N, const int MT, const int Gm) {
     constexpr int BM = WM * TM * 32;
     static_assert(WN * TN * 32 == BN, "block N tile is 128");
     static_assert(WM * WN == 4, "4 waves");
