@@ -109,18 +109,22 @@ __device__ __forceinline__ void load_pass_input(cf (&u)[16], int i, const float 
     }
 }
 
+// Workgroup barrier for LDS traffic only: __syncthreads() also waits for every outstanding GLOBAL load (s_waitcnt vmcnt(0)), which
+// would end the fused iSTFT's prefetch of the next frame at the first barrier of the current one
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // passes P=16 and P=256 reading from / writing to LDS (pass P=1 is done by the caller)
 template <bool INV>
 __device__ __forceinline__ void fft_tail(cf (&u)[16], int i, float *re, float *im, const float *twr, const float *twi) {
-    __syncthreads();
+    lds_barrier();
     load_pass_input<INV>(u, i, re, im);
-    __syncthreads();
+    lds_barrier();
     stockham_pass<INV, 16>(u, i, re, im, twr, twi);
-    __syncthreads();
+    lds_barrier();
     load_pass_input<INV>(u, i, re, im);
-    __syncthreads();
+    lds_barrier();
     stockham_pass<INV, 256>(u, i, re, im, twr, twi);
-    __syncthreads();
+    lds_barrier();
 }
 
 constexpr int kTwLds = kN / 2 + kN / 64;       // padded half table
@@ -335,6 +339,21 @@ __global__ __launch_bounds__(256, 3) void istft_fused_kernel(const float *__rest
 #pragma unroll
         for (int q = 0; q < 4; ++q) acc[j][q][0] = acc[j][q][1] = 0.f;
     const int m_first = hb0 - 5, m_last = hb1 - 3;           // frames that touch blocks [hb0, hb1): block hb takes frames hb - 5 .. hb - 2
+    // The spectrum of the NEXT frame is fetched into registers (32 per thread) while the current frame's passes run: at 117 VGPRs
+    // there is room (three workgroups per CU up to 168), and the barriers between the passes wait for LDS traffic only
+    float pf[32];
+    auto fetch = [&](int m) {
+        const float *src = yt + ((size_t)bs * T + m) * 4 * kBins;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int k = i + 256 * r;
+            pf[4 * r] = src[k]; pf[4 * r + 1] = src[kBins + k]; pf[4 * r + 2] = src[2 * kBins + k]; pf[4 * r + 3] = src[3 * kBins + k];
+        }
+    };
+    {
+        const int m0 = max(m_first, 0);
+        if (m0 <= m_last && m0 < T) fetch(m0);
+    }
 #pragma unroll 1
     for (int m = m_first; m <= m_last; ++m) {
         const bool live = m >= 0 && m < T;                   // workgroup-uniform: frames outside the data are the zero pad
@@ -343,23 +362,21 @@ __global__ __launch_bounds__(256, 3) void istft_fused_kernel(const float *__rest
             // three passes out of the frame loop as invariants and the kernel needs 236 registers (two workgroups per CU)
             int iv = i;
             asm volatile("" : "+v"(iv));
-            const float *src = yt + ((size_t)bs * T + m) * 4 * kBins;
-            __syncthreads();                                 // the previous frame's last LDS reads are done (and the twiddles staged)
-            // (two workgroups share a CU: the other one covers this frame's loads; a register prefetch of the next
-            // frame cost 32 VGPRs and a spill at two workgroups per CU)
+            lds_barrier();                                   // the previous frame's last LDS reads are done (and the twiddles staged)
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
                 const int k = iv + 256 * r;
-                float ar = src[k], ai = src[kBins + k], br = src[2 * kBins + k], bi = src[3 * kBins + k];
+                float ar = pf[4 * r], ai = pf[4 * r + 1], br = pf[4 * r + 2], bi = pf[4 * r + 3];
                 if (k == 0) { ai = 0.f; bi = 0.f; }
                 re[lpad(k)] = ar - bi; im[lpad(k)] = ai + br;
                 if (k > 0) { re[lpad(kN - k)] = ar + bi; im[lpad(kN - k)] = br - ai; }
             }
+            if (m + 1 <= m_last && m + 1 < T) fetch(m + 1);  // in flight under this frame's three passes
             if (iv == 0) { re[lpad(kBins)] = 0.f; im[lpad(kBins)] = 0.f; }
-            __syncthreads();
+            lds_barrier();
             cf u[16];
             load_pass_input<true>(u, iv, re, im);
-            __syncthreads();
+            lds_barrier();
             stockham_pass<true, 1>(u, iv, re, im, twr, twi);
             fft_tail<true>(u, iv, re, im, twr, twi);
 #pragma unroll
