@@ -66,6 +66,7 @@ SIGNATURES = {
     "mi_hmodel_device_bytes": (C.c_int64, [C.c_void_p]),
     "mi_set_two_streams": (C.c_int, [C.c_int32]),
     "mi_set_istft_fused": (C.c_int, [C.c_int32]),
+    "mi_set_transpose_tiles": (C.c_int, [C.c_int32]),
     "mi_profile_begin": (C.c_int, [C.c_void_p]),
     "mi_profile_end": (C.c_int, [C.c_void_p, C.POINTER(MiProfileRow), C.c_int32, C.POINTER(C.c_int32), C.c_void_p]),
     "mi_model_device_bytes": (C.c_int64, [C.c_void_p]),

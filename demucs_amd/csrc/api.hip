@@ -166,6 +166,12 @@ int mi_set_istft_fused(int32_t enabled) {
     return old;
 }
 
+int mi_set_transpose_tiles(int32_t enabled) {
+    const int old = g_transpose_tiles == 7 ? 1 : g_transpose_tiles;
+    g_transpose_tiles = enabled == 1 ? 7 : (enabled & 7);      // 1 = all three round-3 kernels; 2 / 4 / 6: see kernels.h
+    return old;
+}
+
 int mi_profile_begin(void *handle) {
     if (!handle) return set_error(MI_EINVAL, "mi_profile_begin: null handle");
     ((Model *)handle)->prof.begin();

@@ -196,6 +196,77 @@ __global__ __launch_bounds__(256) void stft_frames_kernel(const float *__restric
     }
 }
 
+// The same transform with a workgroup WALKING a run of R consecutive frames (default; the one-frame-per-workgroup kernel above stays
+// behind mi_set_transpose_tiles(1) / MI_TRANSPOSE_TILES as the A/B and the bit-identity reference): twiddles staged and the window
+// read once per run instead of once per frame, the NEXT frame's samples fetched into registers (32 per thread) under the current
+// frame's three passes -- every barrier inside waits for LDS traffic only --, one statistics reduction and atomic pair per run.
+// Same products, same transform, same stores: the spectrogram is bit-identical; the float64 statistics are summed in another
+// order (they were unordered atomics already).
+// grid (ceil(T / R), B), block 256; three workgroups per CU.
+__global__ __launch_bounds__(256, 3) void stft_walk_kernel(const float *__restrict__ mix, int L, int T, int R, int el, int er,
+                                                           const float *__restrict__ window, const float2 *__restrict__ tw,
+                                                           float *__restrict__ zt, double *__restrict__ stats) {
+    MI_FFT_LDS;
+    __shared__ double red[8];
+    const int i = threadIdx.x, b = blockIdx.y;
+    const int t_begin = blockIdx.x * R, t_end = min(T, t_begin + R);
+    if (t_begin >= T) return;
+    stage_twiddles(tw, twr, twi, i);
+    const float *x0 = mix + (size_t)b * 2 * L, *x1 = x0 + L;
+    const int L0 = L + el + er, shift = 1536 - el;           // padding rules: see stft_frames_kernel
+    float wv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) wv[r] = window[i + 256 * r];
+    float pf[32];
+    auto fetch = [&](int t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int q = t * kHop + i + 256 * r - shift;
+            if (q < 0) q = -q;
+            if (q >= L0) q = 2 * (L0 - 1) - q;
+            const int sidx = q - el;
+            const bool in = sidx >= 0 && sidx < L;
+            pf[2 * r] = in ? x0[sidx] : 0.f;
+            pf[2 * r + 1] = in ? x1[sidx] : 0.f;
+        }
+    };
+    fetch(t_begin);
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll 1
+    for (int t = t_begin; t < t_end; ++t) {
+        int iv = i;                                          // opaque per frame: keeps the passes' LDS offsets out of the loop-invariant registers
+        asm volatile("" : "+v"(iv));
+        cf u[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) u[r] = {wv[r] * pf[2 * r], wv[r] * pf[2 * r + 1]};
+        if (t + 1 < t_end) fetch(t + 1);                     // in flight under this frame's passes
+        lds_barrier();                                       // twiddles staged; the previous frame's split reads are done
+        stockham_pass<false, 1>(u, iv, re, im, twr, twi);
+        fft_tail<false>(u, iv, re, im, twr, twi);
+        float *o = zt + ((size_t)b * T + t) * 4 * kBins;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int k = iv + 256 * r;
+            const int km = (kN - k) & (kN - 1);
+            const float ar = re[lpad(k)], ai = im[lpad(k)], br = re[lpad(km)], bi = im[lpad(km)];
+            const float sc = 0.5f / 64.0f;
+            const float v0 = (ar + br) * sc, v1 = (ai - bi) * sc, v2 = (ai + bi) * sc, v3 = (br - ar) * sc;
+            o[k] = v0; o[kBins + k] = v1; o[2 * kBins + k] = v2; o[3 * kBins + k] = v3;
+            s1 += (double)v0 + (double)v1 + (double)v2 + (double)v3;
+            s2 += (double)v0 * v0 + (double)v1 * v1 + (double)v2 * v2 + (double)v3 * v3;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_down(s1, off); s2 += __shfl_down(s2, off); }
+    if ((i & 63) == 0) { red[(i >> 6) * 2] = s1; red[(i >> 6) * 2 + 1] = s2; }
+    __syncthreads();
+    if (i == 0) {
+        double a = red[0] + red[2] + red[4] + red[6], c = red[1] + red[3] + red[5] + red[7];
+        double *dst = stats + ((size_t)b * kStatSlots + (blockIdx.x % kStatSlots)) * 2;
+        atomicAdd(dst, a);
+        atomicAdd(dst + 1, c);
+    }
+}
+
 // zt[b][t][4][2048] -> x[b][4][2048][T] with optional (v - mean) * inv, 32x32 LDS tiles.
 // grid (ceil(T/32), 2048/32, B*4)
 __global__ __launch_bounds__(256) void cac_transpose_kernel(const float *__restrict__ zt, int T, const float2 *__restrict__ norm,
@@ -218,6 +289,115 @@ __global__ __launch_bounds__(256) void cac_transpose_kernel(const float *__restr
         if (t < T) x[(((size_t)b * 4 + c) * kBins + k) * Tp + t] = (tile[tx][ty + 8 * r] - mean) * inv;
     }
 }
+
+// Strip form of the two transposes (default; the 32 x 32 tile kernels stay behind MI_TRANSPOSE_TILES=1 as the A/B and the
+// bit-identity reference).  A workgroup owns 32 bins x up to kStripT frames of one plane.  On the conv-layout side that strip is
+// ONE contiguous run of 32 rows (43 KB at T = 336), moved as 16-byte accesses: no tile of it straddles a 128-byte line.  With
+// tiles, every odd row of 336 floats starts 64 bytes into a line, each of the ten inner tile boundaries of a row splits a line
+// between two workgroups, and consecutive workgroups sit on different XCDs: both L2s fetched the line (PMC 1.26 x the
+// algorithmic bytes for the inverse side) and 4.5 % of the lanes idled in the half-empty eleventh tile.  On the frame-major side
+// a half-wave moves one aligned 128-byte run of bins, as before.  Values and arithmetic are those of the tile kernels.
+constexpr int kStripT = 336;
+__device__ __forceinline__ int strip_pitch(int tc) { return tc | 1; }       // odd: the bin-major column accesses spread over the banks
+
+// grid (2048/32, B*4, ceil(T / kStripT)); dynamic LDS 32 * strip_pitch(min(T, kStripT)) floats
+__global__ __launch_bounds__(256) void cac_transpose_strip_kernel(const float *__restrict__ zt, int T, const float2 *__restrict__ norm,
+                                                                  float *__restrict__ x, int Tp) {
+    extern __shared__ float strip[];
+    const int bc = blockIdx.y, b = bc >> 2, c = bc & 3, k0 = blockIdx.x * 32;
+    const int t0 = blockIdx.z * kStripT, tc = min(kStripT, T - t0), PT = strip_pitch(min(T, kStripT));
+    const int i = threadIdx.x, tx = i & 31, ty = i >> 5;
+    float mean = 0.f, inv = 1.f;
+    if (norm) { float2 m = norm[b]; mean = m.x; inv = m.y; }
+    // a thread's loads go out in batches of eight (one 128-byte run of bins per half-wave and frame)
+    const float *zsrc = zt + (((size_t)b * T + t0) * 4 + c) * kBins + k0 + tx;
+#pragma unroll 1
+    for (int tb = ty; tb < tc; tb += 64) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int t = tb + 8 * u; v[u] = t < tc ? zsrc[(size_t)t * 4 * kBins] : 0.f; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int t = tb + 8 * u; if (t < tc) strip[tx * PT + t] = v[u]; }
+    }
+    __syncthreads();
+    const int lane = i & 63, w = i >> 6;
+    const bool vec = ((tc | Tp) & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;       // t0 is a multiple of 4
+    float *rows = x + ((size_t)bc * kBins + k0) * Tp + t0;
+    if (vec) {
+        const int n4 = tc >> 2;                                             // <= 84: two 16-byte stores per lane and row
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int k = w + 4 * r;
+            const float *sr = strip + k * PT;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int t4 = lane + 64 * h;
+                if (t4 < n4) {
+                    float4 v;
+                    v.x = (sr[4 * t4] - mean) * inv; v.y = (sr[4 * t4 + 1] - mean) * inv;
+                    v.z = (sr[4 * t4 + 2] - mean) * inv; v.w = (sr[4 * t4 + 3] - mean) * inv;
+                    reinterpret_cast<float4 *>(rows + (size_t)k * Tp)[t4] = v;
+                }
+            }
+        }
+    } else {
+#pragma unroll 1
+        for (int k = w; k < 32; k += 4)
+            for (int t = lane; t < tc; t += 64) rows[(size_t)k * Tp + t] = (strip[k * PT + t] - mean) * inv;
+    }
+}
+
+// grid (2048/32, B*S*4, ceil(T / kStripT)); dynamic LDS as above
+__global__ __launch_bounds__(256) void spec_transpose_strip_kernel(const float *__restrict__ y, int T, int S4, const float2 *__restrict__ denorm,
+                                                                   float *__restrict__ yt, int Tp) {
+    extern __shared__ float strip[];
+    const int bc = blockIdx.y, b = bc / S4, sc = bc % S4, s = sc >> 2, c = sc & 3, k0 = blockIdx.x * 32;
+    const int t0 = blockIdx.z * kStripT, tc = min(kStripT, T - t0), PT = strip_pitch(min(T, kStripT));
+    const int i = threadIdx.x, lane = i & 63, w = i >> 6;
+    float mean = 0.f, std = 1.f;
+    if (denorm) { float2 m = denorm[b]; mean = m.x; std = m.y; }
+    const bool vec = ((tc | Tp) & 3) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0;
+    const float *rows = y + ((size_t)bc * kBins + k0) * Tp + t0;
+    if (vec) {
+        // the strip is one contiguous run when the pitch equals T; a thread's sixteen 16-byte loads are in flight together
+        const int n4 = tc >> 2;
+        float4 v[8][2];
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int t4 = lane + 64 * h;
+                if (t4 < n4) v[r][h] = reinterpret_cast<const float4 *>(rows + (size_t)(w + 4 * r) * Tp)[t4];
+            }
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int t4 = lane + 64 * h;
+                float *sr = strip + (w + 4 * r) * PT + 4 * t4;
+                if (t4 < n4) {
+                    sr[0] = v[r][h].x * std + mean; sr[1] = v[r][h].y * std + mean;
+                    sr[2] = v[r][h].z * std + mean; sr[3] = v[r][h].w * std + mean;
+                }
+            }
+    } else {
+#pragma unroll 1
+        for (int k = w; k < 32; k += 4)
+            for (int t = lane; t < tc; t += 64) strip[k * PT + t] = rows[(size_t)k * Tp + t] * std + mean;
+    }
+    __syncthreads();
+    const int tx = i & 31, ty = i >> 5;
+    for (int t = ty; t < tc; t += 8) yt[((((size_t)b * (S4 >> 2) + s) * T + t0 + t) * 4 + c) * kBins + k0 + tx] = strip[tx * PT + t];
+}
+
+// bit 0: one-frame-per-workgroup STFT, bit 1: tile cac_transpose, bit 2: tile spec_transpose (mi_set_transpose_tiles(1) sets all three)
+static int transpose_tiles_from_env() {
+    const char *e = getenv("MI_TRANSPOSE_TILES");
+    if (!e) return 0;
+    const int v = atoi(e);
+    return v > 1 ? (v & 7) : 7;
+}
+int g_transpose_tiles = transpose_tiles_from_env();
 
 // ---------------------------------------------------------------------------------------------
 // iSTFT.  (1) y[b][S*4][2048][T] (decoder output, CaC) -> frame-major yt[b][s][t][4][2048] with
@@ -417,6 +597,8 @@ int g_istft_fused = getenv("MI_ISTFT_SPLIT") == nullptr ? 1 : 0;
 // ---------------------------------------------------------------------------------------------
 // host-side launchers
 // ---------------------------------------------------------------------------------------------
+static size_t strip_lds_bytes(int T) { return (size_t)32 * (std::min(T, kStripT) | 1) * sizeof(float); }
+
 int launch_stft_frames(const float *mix, int B, int L, const FftTables &tb, float *zt, double *stats, hipStream_t st) {
     const int T = ceil_div(L, kHop);
     MI_REQUIRE(L >= 1, "stft: empty input");
@@ -424,13 +606,23 @@ int launch_stft_frames(const float *mix, int B, int L, const FftTables &tb, floa
     const int left = 1536, right = 1536 + T * kHop - L, max_pad = std::max(left, right);
     int el = 0, er = 0;
     if (L <= max_pad) { const int extra = max_pad - L + 1; er = std::min(right, extra); el = extra - er; }
-    hipLaunchKernelGGL(stft_frames_kernel, dim3(T, B), dim3(256), 0, st, mix, L, T, el, er, tb.window, tb.twiddle, zt, stats);
+    if (g_transpose_tiles & 1) {
+        hipLaunchKernelGGL(stft_frames_kernel, dim3(T, B), dim3(256), 0, st, mix, L, T, el, er, tb.window, tb.twiddle, zt, stats);
+    } else {
+        // runs of R consecutive frames per workgroup, about two waves of workgroups over the chip's 768 slots (B = 31, T = 336: R = 7)
+        const int runs = std::max(1, std::min(T, ceil_div(1536, B))), R = ceil_div(T, runs);
+        hipLaunchKernelGGL(stft_walk_kernel, dim3(ceil_div(T, R), B), dim3(256), 0, st, mix, L, T, R, el, er, tb.window, tb.twiddle, zt, stats);
+    }
     MI_CHECK_LAUNCH();
     return MI_OK;
 }
 
 int launch_cac_transpose(const float *zt, int B, int T, const float2 *norm, float *x, hipStream_t st, int x_pitch) {
-    hipLaunchKernelGGL(cac_transpose_kernel, dim3(ceil_div(T, 32), kBins / 32, B * 4), dim3(256), 0, st, zt, T, norm, x, x_pitch ? x_pitch : T);
+    if (g_transpose_tiles & 2)
+        hipLaunchKernelGGL(cac_transpose_kernel, dim3(ceil_div(T, 32), kBins / 32, B * 4), dim3(256), 0, st, zt, T, norm, x, x_pitch ? x_pitch : T);
+    else
+        hipLaunchKernelGGL(cac_transpose_strip_kernel, dim3(kBins / 32, B * 4, ceil_div(T, kStripT)), dim3(256), strip_lds_bytes(T), st, zt, T, norm,
+                           x, x_pitch ? x_pitch : T);
     MI_CHECK_LAUNCH();
     return MI_OK;
 }
@@ -438,7 +630,11 @@ int launch_cac_transpose(const float *zt, int B, int T, const float2 *norm, floa
 int launch_istft(const float *y, int B, int S, int L, const float2 *denorm, const float *xt, const float2 *denorm_t,
                  const FftTables &tb, float *yt, float *fr, float *out, hipStream_t st, int xt_pitch, int y_pitch) {
     const int T = ceil_div(L, kHop);
-    hipLaunchKernelGGL(spec_transpose_kernel, dim3(ceil_div(T, 32), kBins / 32, B * S * 4), dim3(256), 0, st, y, T, S * 4, denorm, yt, y_pitch ? y_pitch : T);
+    if (g_transpose_tiles & 4)
+        hipLaunchKernelGGL(spec_transpose_kernel, dim3(ceil_div(T, 32), kBins / 32, B * S * 4), dim3(256), 0, st, y, T, S * 4, denorm, yt, y_pitch ? y_pitch : T);
+    else
+        hipLaunchKernelGGL(spec_transpose_strip_kernel, dim3(kBins / 32, B * S * 4, ceil_div(T, kStripT)), dim3(256), strip_lds_bytes(T), st, y, T, S * 4,
+                           denorm, yt, y_pitch ? y_pitch : T);
     MI_CHECK_LAUNCH();
     // default: the fused frame + overlap-add kernel; MI_ISTFT_SPLIT=1 / mi_set_istft_fused(0): the two separate kernels (A/B, and
     // the bit-identity test of the fused one)

@@ -29,6 +29,7 @@ int launch_istft(const float *y, int B, int S, int L, const float2 *denorm, cons
                  const FftTables &tb, float *yt, float *fr, float *out, hipStream_t st, int xt_pitch = 0 /* row pitch of xt, 0 = L */,
                  int y_pitch = 0 /* row pitch of y along T, 0 = T */);
 
+extern int g_transpose_tiles;  // fft.hip: round-3 kernels around the transforms; bit 0: one STFT frame per workgroup, bit 1: tile cac_transpose, bit 2: tile spec_transpose
 extern int g_istft_fused;      // fft.hip: 1 = fused inverse-transform + overlap-add kernel (default), 0 = the two separate kernels
 
 // norms.hip

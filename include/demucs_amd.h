@@ -18,7 +18,7 @@
  *     workspace of the htdemucs engine, which every handle created on the same device with the same (n_sources,
  *     segment_length, max_batch, float32 / half) shares -- a bag of four fine-tuned models holds its ~0.57 GB per batched
  *     segment once: such handles must run one after the other on one stream (what apply_model's bag loop does), never
- *     concurrently; hdemucs handles own their workspace; (2) the schedule switches mi_set_two_streams / mi_set_istft_fused
+ *     concurrently; hdemucs handles own their workspace; (2) the schedule switches mi_set_two_streams / mi_set_istft_fused / mi_set_transpose_tiles
  *     and the MI_* environment variables (read once); (3) two small device blocks every launch may use: a 256-float sink for
  *     masked stores and 256 bytes of zeros (the source of out-of-frame LDS-DMA transfers).  A forward also uses a side stream
  *     owned by its handle; it is joined on the caller's stream before the call returns.
@@ -121,6 +121,12 @@ int mi_set_two_streams(int32_t enabled);
  *   (frames to memory, then a gather): same summation order, bit-identical output -- kept for A/B runs and as the check of the
  *   fused kernel.  Process-wide; returns the previous setting.  Initial value: 1 unless MI_ISTFT_SPLIT is set. */
 int mi_set_istft_fused(int32_t enabled);
+/* mi_set_transpose_tiles: the layout changes either side of the transforms (frame-major scratch <-> the conv layout
+ *   x[b][c][bin][frame] of demucs/htdemucs.py:420-471) run as STRIP kernels (0, the default: a workgroup moves 32 bins x all frames
+ *   of a plane, one contiguous run on the conv-layout side); 1 selects the 32 x 32 tile kernels of rounds 1-3: same values, same
+ *   arithmetic, bit-identical output -- kept for A/B runs and as the check of the strip kernels.  Process-wide; returns the previous
+ *   setting.  Initial value: 0 unless MI_TRANSPOSE_TILES is set. */
+int mi_set_transpose_tiles(int32_t enabled);
 int mi_profile_begin(void *handle);
 int mi_profile_end(void *handle, mi_profile_row *rows, int32_t max_rows, int32_t *n_rows, void *stream);
 

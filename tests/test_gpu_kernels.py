@@ -104,6 +104,30 @@ def test_fused_istft_is_bit_identical_to_the_separate_kernels(lib, L):
     assert bool(torch.isfinite(outs[0]).all()) and torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("L", [SL, 44100 * 3 + 17, 5000, 44 * 44100 + 3])
+def test_strip_transposes_are_bit_identical_to_the_tile_kernels(lib, L):
+    """Both layout changes around the transforms (cac_transpose / spec_transpose) move 32 bins x all frames per workgroup by
+    default; the 32 x 32 tile kernels compute the same values with the same arithmetic: equal bits for the normalised CaC
+    spectrogram and for the waveform, at the segment length (one strip, 16-byte accesses), at frame counts that are no multiple of
+    four (4-byte accesses), at a short input and at a 44-second chunk (several strips per row)."""
+    T = -(-L // 1024)
+    mix = torch.from_numpy(synth_mix(6, L, "noise"))[None].repeat(2, 1, 1).contiguous().cuda()
+    x = rnd(2, 2, 4, 2048, T, seed=8).float().cuda()
+    got = []
+    for tiles in (0, 1):
+        old = lib.mi_set_transpose_tiles(tiles)
+        try:
+            spec = torch.full((2, 4, 2048, T), float("nan"), device="cuda")
+            _lib.check(lib.mi_stft_cac(mix.data_ptr(), 2, L, spec.data_ptr(), stream()), "mi_stft_cac")
+            wav = torch.full((2, 2, 2, L), float("nan"), device="cuda")
+            _lib.check(lib.mi_istft_cac(x.data_ptr(), 2, 2, L, wav.data_ptr(), stream()), "mi_istft_cac")
+        finally:
+            lib.mi_set_transpose_tiles(old)
+        got.append((spec.cpu(), wav.cpu()))
+    assert bool(torch.isfinite(got[0][0]).all()) and bool(torch.isfinite(got[0][1]).all())
+    assert torch.equal(got[0][0], got[1][0]) and torch.equal(got[0][1], got[1][1])
+
+
 # ------------------------------------------------------------------------------------------------
 from gpu_helpers import (EPI_BIAS_STATS, EPI_CONVTR, EPI_GLU, EPI_GN_GLU, EPI_LINEAR, EPI_STATS_ONLY, FLAG_EMB,  # noqa: E402
                          FLAG_GELU, FLAG_RES, FLAG_SCALE, FLAG_TR_FREQ, SLOTS, conv_call, ktab, maxerr, pack_vec, pack_w)
