@@ -298,96 +298,87 @@ __global__ __launch_bounds__(256) void cac_transpose_kernel(const float *__restr
 // algorithmic bytes for the inverse side) and 4.5 % of the lanes idled in the half-empty eleventh tile.  On the frame-major side
 // a half-wave moves one aligned 128-byte run of bins, as before.  Values and arithmetic are those of the tile kernels.
 constexpr int kStripT = 336;
-__device__ __forceinline__ int strip_pitch(int tc) { return tc | 1; }       // odd: the bin-major column accesses spread over the banks
+__device__ __host__ __forceinline__ int strip_pitch(int tc) { return tc | 1; }       // odd: the bin-major column accesses spread over the banks
 
-// grid (2048/32, B*4, ceil(T / kStripT)); dynamic LDS 32 * strip_pitch(min(T, kStripT)) floats
+// KB bins x TS frames per workgroup: 32 x 336, the whole row of a segment (64 x 168 -- 256-byte runs on the frame-major side, 672-byte
+// runs on the conv-layout side -- measured 153 / 548 us against 132 / 501 us).  The frame-major side is walked a few frames at a time (its runs lie 32 KB apart: batching them
+// opened 64 DRAM pages per workgroup at once and measured slower); the contiguous side issues all of a thread's 16-byte accesses
+// together.
+// grid (2048/KB, B*4, ceil(T / TS)); dynamic LDS KB * strip_pitch(min(T, TS)) floats
+template <int KB, int TS>
 __global__ __launch_bounds__(256) void cac_transpose_strip_kernel(const float *__restrict__ zt, int T, const float2 *__restrict__ norm,
                                                                   float *__restrict__ x, int Tp) {
     extern __shared__ float strip[];
-    const int bc = blockIdx.y, b = bc >> 2, c = bc & 3, k0 = blockIdx.x * 32;
-    const int t0 = blockIdx.z * kStripT, tc = min(kStripT, T - t0), PT = strip_pitch(min(T, kStripT));
-    const int i = threadIdx.x, tx = i & 31, ty = i >> 5;
+    constexpr int G = 256 / KB;                                             // frames per pass on the frame-major side
+    const int bc = blockIdx.y, b = bc >> 2, c = bc & 3, k0 = blockIdx.x * KB;
+    const int t0 = blockIdx.z * TS, tc = min(TS, T - t0), PT = strip_pitch(min(T, TS));
+    const int i = threadIdx.x, tx = i % KB, ty = i / KB;
     float mean = 0.f, inv = 1.f;
     if (norm) { float2 m = norm[b]; mean = m.x; inv = m.y; }
-    // a thread's loads go out in batches of eight (one 128-byte run of bins per half-wave and frame)
-    const float *zsrc = zt + (((size_t)b * T + t0) * 4 + c) * kBins + k0 + tx;
-#pragma unroll 1
-    for (int tb = ty; tb < tc; tb += 64) {
-        float v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { const int t = tb + 8 * u; v[u] = t < tc ? zsrc[(size_t)t * 4 * kBins] : 0.f; }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { const int t = tb + 8 * u; if (t < tc) strip[tx * PT + t] = v[u]; }
-    }
+    for (int t = ty; t < tc; t += G) strip[tx * PT + t] = zt[(((size_t)b * T + t0 + t) * 4 + c) * kBins + k0 + tx];
     __syncthreads();
-    const int lane = i & 63, w = i >> 6;
     const bool vec = ((tc | Tp) & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;       // t0 is a multiple of 4
     float *rows = x + ((size_t)bc * kBins + k0) * Tp + t0;
     if (vec) {
-        const int n4 = tc >> 2;                                             // <= 84: two 16-byte stores per lane and row
+        constexpr int N4 = TS / 4, J = (KB * N4 + 255) / 256;
+        const int n4 = tc >> 2;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const int k = w + 4 * r;
-            const float *sr = strip + k * PT;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int t4 = lane + 64 * h;
-                if (t4 < n4) {
-                    float4 v;
-                    v.x = (sr[4 * t4] - mean) * inv; v.y = (sr[4 * t4 + 1] - mean) * inv;
-                    v.z = (sr[4 * t4 + 2] - mean) * inv; v.w = (sr[4 * t4 + 3] - mean) * inv;
-                    reinterpret_cast<float4 *>(rows + (size_t)k * Tp)[t4] = v;
-                }
+        for (int j = 0; j < J; ++j) {
+            const int f = i + 256 * j, k = f / N4, t4 = f % N4;
+            if (k < KB && t4 < n4) {
+                const float *sr = strip + k * PT + 4 * t4;
+                float4 v;
+                v.x = (sr[0] - mean) * inv; v.y = (sr[1] - mean) * inv; v.z = (sr[2] - mean) * inv; v.w = (sr[3] - mean) * inv;
+                reinterpret_cast<float4 *>(rows + (size_t)k * Tp)[t4] = v;
             }
         }
     } else {
+        const int lane = i & 63, w = i >> 6;
 #pragma unroll 1
-        for (int k = w; k < 32; k += 4)
+        for (int k = w; k < KB; k += 4)
             for (int t = lane; t < tc; t += 64) rows[(size_t)k * Tp + t] = (strip[k * PT + t] - mean) * inv;
     }
 }
 
-// grid (2048/32, B*S*4, ceil(T / kStripT)); dynamic LDS as above
+// grid (2048/KB, B*S*4, ceil(T / TS)); dynamic LDS as above
+template <int KB, int TS>
 __global__ __launch_bounds__(256) void spec_transpose_strip_kernel(const float *__restrict__ y, int T, int S4, const float2 *__restrict__ denorm,
                                                                    float *__restrict__ yt, int Tp) {
     extern __shared__ float strip[];
-    const int bc = blockIdx.y, b = bc / S4, sc = bc % S4, s = sc >> 2, c = sc & 3, k0 = blockIdx.x * 32;
-    const int t0 = blockIdx.z * kStripT, tc = min(kStripT, T - t0), PT = strip_pitch(min(T, kStripT));
-    const int i = threadIdx.x, lane = i & 63, w = i >> 6;
+    constexpr int G = 256 / KB;
+    const int bc = blockIdx.y, b = bc / S4, sc = bc % S4, s = sc >> 2, c = sc & 3, k0 = blockIdx.x * KB;
+    const int t0 = blockIdx.z * TS, tc = min(TS, T - t0), PT = strip_pitch(min(T, TS));
+    const int i = threadIdx.x;
     float mean = 0.f, std = 1.f;
     if (denorm) { float2 m = denorm[b]; mean = m.x; std = m.y; }
     const bool vec = ((tc | Tp) & 3) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0;
     const float *rows = y + ((size_t)bc * kBins + k0) * Tp + t0;
     if (vec) {
-        // the strip is one contiguous run when the pitch equals T; a thread's sixteen 16-byte loads are in flight together
+        constexpr int N4 = TS / 4, J = (KB * N4 + 255) / 256;
         const int n4 = tc >> 2;
-        float4 v[8][2];
+        float4 v[J];
 #pragma unroll
-        for (int r = 0; r < 8; ++r)
+        for (int j = 0; j < J; ++j) {
+            const int f = i + 256 * j, k = f / N4, t4 = f % N4;
+            if (k < KB && t4 < n4) v[j] = reinterpret_cast<const float4 *>(rows + (size_t)k * Tp)[t4];
+        }
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int t4 = lane + 64 * h;
-                if (t4 < n4) v[r][h] = reinterpret_cast<const float4 *>(rows + (size_t)(w + 4 * r) * Tp)[t4];
+        for (int j = 0; j < J; ++j) {
+            const int f = i + 256 * j, k = f / N4, t4 = f % N4;
+            if (k < KB && t4 < n4) {
+                float *sr = strip + k * PT + 4 * t4;
+                sr[0] = v[j].x * std + mean; sr[1] = v[j].y * std + mean; sr[2] = v[j].z * std + mean; sr[3] = v[j].w * std + mean;
             }
-#pragma unroll
-        for (int r = 0; r < 8; ++r)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int t4 = lane + 64 * h;
-                float *sr = strip + (w + 4 * r) * PT + 4 * t4;
-                if (t4 < n4) {
-                    sr[0] = v[r][h].x * std + mean; sr[1] = v[r][h].y * std + mean;
-                    sr[2] = v[r][h].z * std + mean; sr[3] = v[r][h].w * std + mean;
-                }
-            }
+        }
     } else {
+        const int lane = i & 63, w = i >> 6;
 #pragma unroll 1
-        for (int k = w; k < 32; k += 4)
+        for (int k = w; k < KB; k += 4)
             for (int t = lane; t < tc; t += 64) strip[k * PT + t] = rows[(size_t)k * Tp + t] * std + mean;
     }
     __syncthreads();
-    const int tx = i & 31, ty = i >> 5;
-    for (int t = ty; t < tc; t += 8) yt[((((size_t)b * (S4 >> 2) + s) * T + t0 + t) * 4 + c) * kBins + k0 + tx] = strip[tx * PT + t];
+    const int tx = i % KB, ty = i / KB;
+    for (int t = ty; t < tc; t += G) yt[((((size_t)b * (S4 >> 2) + s) * T + t0 + t) * 4 + c) * kBins + k0 + tx] = strip[tx * PT + t];
 }
 
 // bit 0: one-frame-per-workgroup STFT, bit 1: tile cac_transpose, bit 2: tile spec_transpose (mi_set_transpose_tiles(1) sets all three)
@@ -597,7 +588,7 @@ int g_istft_fused = getenv("MI_ISTFT_SPLIT") == nullptr ? 1 : 0;
 // ---------------------------------------------------------------------------------------------
 // host-side launchers
 // ---------------------------------------------------------------------------------------------
-static size_t strip_lds_bytes(int T) { return (size_t)32 * (std::min(T, kStripT) | 1) * sizeof(float); }
+static size_t strip_lds_bytes(int KB, int T, int TS) { return (size_t)KB * strip_pitch(std::min(T, TS)) * sizeof(float); }
 
 int launch_stft_frames(const float *mix, int B, int L, const FftTables &tb, float *zt, double *stats, hipStream_t st) {
     const int T = ceil_div(L, kHop);
@@ -621,8 +612,8 @@ int launch_cac_transpose(const float *zt, int B, int T, const float2 *norm, floa
     if (g_transpose_tiles & 2)
         hipLaunchKernelGGL(cac_transpose_kernel, dim3(ceil_div(T, 32), kBins / 32, B * 4), dim3(256), 0, st, zt, T, norm, x, x_pitch ? x_pitch : T);
     else
-        hipLaunchKernelGGL(cac_transpose_strip_kernel, dim3(kBins / 32, B * 4, ceil_div(T, kStripT)), dim3(256), strip_lds_bytes(T), st, zt, T, norm,
-                           x, x_pitch ? x_pitch : T);
+        hipLaunchKernelGGL((cac_transpose_strip_kernel<32, kStripT>), dim3(kBins / 32, B * 4, ceil_div(T, kStripT)), dim3(256), strip_lds_bytes(32, T, kStripT), st,
+                           zt, T, norm, x, x_pitch ? x_pitch : T);
     MI_CHECK_LAUNCH();
     return MI_OK;
 }
@@ -633,8 +624,8 @@ int launch_istft(const float *y, int B, int S, int L, const float2 *denorm, cons
     if (g_transpose_tiles & 4)
         hipLaunchKernelGGL(spec_transpose_kernel, dim3(ceil_div(T, 32), kBins / 32, B * S * 4), dim3(256), 0, st, y, T, S * 4, denorm, yt, y_pitch ? y_pitch : T);
     else
-        hipLaunchKernelGGL(spec_transpose_strip_kernel, dim3(kBins / 32, B * S * 4, ceil_div(T, kStripT)), dim3(256), strip_lds_bytes(T), st, y, T, S * 4,
-                           denorm, yt, y_pitch ? y_pitch : T);
+        hipLaunchKernelGGL((spec_transpose_strip_kernel<32, kStripT>), dim3(kBins / 32, B * S * 4, ceil_div(T, kStripT)), dim3(256), strip_lds_bytes(32, T, kStripT),
+                           st, y, T, S * 4, denorm, yt, y_pitch ? y_pitch : T);
     MI_CHECK_LAUNCH();
     // default: the fused frame + overlap-add kernel; MI_ISTFT_SPLIT=1 / mi_set_istft_fused(0): the two separate kernels (A/B, and
     // the bit-identity test of the fused one)

@@ -150,7 +150,12 @@ __device__ __forceinline__ void conv_epilogue(const mi_conv_desc &d, f32x16 (&ac
             // keep the epilogue of one 32x32 accumulator tile together: without the fence hipcc copies all
             // accumulators out of the AGPR file first and the VGPR allocation (not the main loop) caps occupancy
             __builtin_amdgcn_sched_barrier(0);
-            const int mbase = m0 + (wm * TM + a) * 32 + 4 * lh;
+            int mbase = m0 + (wm * TM + a) * 32 + 4 * lh;
+            // opaque per accumulator tile: otherwise the row offsets m * cs, the bounds tests and the per-row vector addresses of ALL
+            // TM row blocks are computed once, shared between the TN column blocks and kept live across the whole epilogue --
+            // more address registers than the budget allows next to a tile's working set, so they went to scratch
+            asm volatile("" : "+v"(mbase));
+            const f32x16 &tacc = acc[a][b];
             float biasr[16], auxr[16], aux2r[16];        // this tile's per-row vectors (float4 loads, L1/L2 hits)
             load_rows16(d.bias, mbase, biasr);
             if (EPI == MI_EPI_LINEAR && (LFLAGS & (MI_FLAG_SCALE | MI_FLAG_LN))) load_rows16(d.scale, mbase, auxr);
@@ -175,8 +180,8 @@ __device__ __forceinline__ void conv_epilogue(const mi_conv_desc &d, f32x16 (&ac
                 for (int r = 0; r < 16; ++r) {
                     const int m = mbase + (r & 3) + 8 * (r >> 2);
                     float v;
-                    if (LFLAGS & MI_FLAG_LN) v = lnstat.y * (acc[a][b][r] - lnstat.x * auxr[r]) + biasr[r];
-                    else v = acc[a][b][r] + biasr[r];
+                    if (LFLAGS & MI_FLAG_LN) v = lnstat.y * (tacc[r] - lnstat.x * auxr[r]) + biasr[r];
+                    else v = tacc[r] + biasr[r];
                     if (LFLAGS & MI_FLAG_GELU) v = gelu_exact(v);
                     if (LFLAGS & MI_FLAG_SCALE) v *= auxr[r];
                     if (LFLAGS & MI_FLAG_RES) v += resv[r];
@@ -242,7 +247,7 @@ __device__ __forceinline__ void conv_epilogue(const mi_conv_desc &d, f32x16 (&ac
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
                     const int m = mbase + (r & 3) + 8 * (r >> 2);   // even row: value, m+1: gate
-                    float va = acc[a][b][r] + biasr[r], vg = acc[a][b][r + 1] + biasr[r + 1];
+                    float va = tacc[r] + biasr[r], vg = tacc[r + 1] + biasr[r + 1];
                     if (EPI == MI_EPI_GN_GLU) {
                         va = (va - gmean) * grstd * auxr[r] + aux2r[r];
                         vg = (vg - gmean) * grstd * auxr[r + 1] + aux2r[r + 1];
@@ -270,17 +275,17 @@ __device__ __forceinline__ void conv_epilogue(const mi_conv_desc &d, f32x16 (&ac
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int m = mbase + (r & 3) + 8 * (r >> 2);
-                    const float v = acc[a][b][r] + biasr[r];
+                    const float v = tacc[r] + biasr[r];
                     const bool ok = c.valid && m < d.M;
                     if (EPI == MI_EPI_BIAS_STATS)
                         *(ok ? d.y + ((size_t)c.b * d.y_bstride + (size_t)m * d.y_cstride + c.p) : sink) = v;
                     s1 += ok ? v : 0.f; s2 += ok ? v * v : 0.f;
                 }
             } else if (EPI == MI_EPI_CONVTR) {
-                if (tr_lg == 1) convtr_tile<1, 0>(d, acc[a][b], biasr, trc, mbase, sink);
-                else if (!(d.flags & MI_FLAG_GELU)) convtr_tile<2, 0>(d, acc[a][b], biasr, trc, mbase, sink);
-                else if (!(d.flags & MI_FLAG_IMG)) convtr_tile<2, MI_FLAG_GELU | MI_FLAG_RES>(d, acc[a][b], biasr, trc, mbase, sink);
-                else convtr_tile<2, MI_FLAG_GELU | MI_FLAG_RES | MI_FLAG_IMG>(d, acc[a][b], biasr, trc, mbase, sink);
+                if (tr_lg == 1) convtr_tile<1, 0>(d, tacc, biasr, trc, mbase, sink);
+                else if (!(d.flags & MI_FLAG_GELU)) convtr_tile<2, 0>(d, tacc, biasr, trc, mbase, sink);
+                else if (!(d.flags & MI_FLAG_IMG)) convtr_tile<2, MI_FLAG_GELU | MI_FLAG_RES>(d, tacc, biasr, trc, mbase, sink);
+                else convtr_tile<2, MI_FLAG_GELU | MI_FLAG_RES | MI_FLAG_IMG>(d, tacc, biasr, trc, mbase, sink);
             }
         }
         if (EPI == MI_EPI_BIAS_STATS || EPI == MI_EPI_STATS_ONLY || (EPI == MI_EPI_LINEAR && (LFLAGS & MI_FLAG_STATS))) {
