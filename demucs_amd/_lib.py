@@ -64,6 +64,7 @@ SIGNATURES = {
     "mi_hmodel_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "mi_hmodel_tap": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.c_void_p]),
     "mi_hmodel_device_bytes": (C.c_int64, [C.c_void_p]),
+    "mi_hmodel_status": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mi_set_two_streams": (C.c_int, [C.c_int32]),
     "mi_set_istft_fused": (C.c_int, [C.c_int32]),
     "mi_set_transpose_tiles": (C.c_int, [C.c_int32]),

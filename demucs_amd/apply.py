@@ -623,6 +623,7 @@ def _apply_split_device(model, mix, common, callback, callback_arg) -> torch.Ten
             out[b] = acc.view(S, channels, length).to(mix.device)
     if bar is not None:
         bar.close()
+    model.check()          # a time-out of the LAST forward's recurrence would otherwise pass unnoticed (include/demucs_amd.h)
     return out
 
 

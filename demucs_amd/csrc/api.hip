@@ -152,6 +152,16 @@ int mi_hmodel_tap(void *handle, const char *name, float *dst_dev, int32_t B, int
     return MI_OK;
 }
 
+int mi_hmodel_status(void *handle, void *stream) {
+    if (!handle) return set_error(MI_EINVAL, "mi_hmodel_status: null handle");
+    MI_HIP(hipStreamSynchronize((hipStream_t)stream));
+    HModel *m = (HModel *)handle;
+    MI_REQUIRE(!m->lstm_timeout || *(volatile unsigned *)m->lstm_timeout == 0,
+               "a forward's persistent LSTM kernel timed out waiting for its hidden-state exchange (GPU shared with another process's "
+               "persistent kernels?): its output and every later one are invalid; MI_LSTM_STEPS=1 selects the one-launch-per-step recurrence");
+    return MI_OK;
+}
+
 int64_t mi_hmodel_device_bytes(void *handle) { return handle ? ((HModel *)handle)->device_bytes + ((HModel *)handle)->hws_bytes : 0; }
 
 int mi_set_two_streams(int32_t enabled) {

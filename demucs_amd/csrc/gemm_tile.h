@@ -87,35 +87,42 @@ __device__ __forceinline__ void convtr_tile(const mi_conv_desc &d, const f32x16 
     constexpr bool gelu = F & MI_FLAG_GELU, resf = F & MI_FLAG_RES, imgf = F & MI_FLAG_IMG;
     // rows of the tile: m = mbase + j, j = (r & 3) + 8 * (r >> 2), mbase % 4 == 0 -> co = co0 + (j >> LG), phase = j & (stride - 1)
     const int co0 = mbase >> LG, cout = d.M >> LG;
-    int off[16];
-    float resv[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int j = (r & 3) + 8 * (r >> 2), co = co0 + (j >> LG);
-        const int rowoff = co < cout ? co * cs : kTrBad;          // one multiply per distinct channel after CSE
-        off[r] = rowoff + t.po[j & ((1 << LG) - 1)];
-    }
-    if (resf) {
-        const float *const rcol = d.res + t.colbase;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) resv[r] = rcol[max(off[r], 0)];
-    }
     float *const ycol = d.y + t.colbase;
+    const float *const rcol = d.res + t.colbase;
     unsigned short *const yimg = reinterpret_cast<unsigned short *>(d.yh) + t.imgbase;
+    // eight rows at a time: with all 16 offsets (and their clamped 64-bit forms for the residual loads) live at once the 96-row
+    // tile spilled 104 bytes per lane at four workgroups per CU
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        float v = acc[r] + biasr[r];
-        if (gelu) v = gelu_exact(v);
-        if (resf) v += resv[r];
-        if (imgf) {
-            // the only reader is the next layer's k x k conv (gemm_tap.hip): 16-bit, [co / 8][position][8]
-            const int j = (r & 3) + 8 * (r >> 2), co = co0 + (j >> LG);
-            const size_t chan = (size_t)(co >> 3) * d.yh_n * 8 + (co & 7);
-            const int pos8 = (off[r] - co * cs) * 8;
-            if (off[r] >= 0) yimg[chan + pos8] = (unsigned short)(pack_half2(d.half, v, 0.f) & 0xffffu);
-        } else {
-            *(off[r] >= 0 ? ycol + off[r] : sink) = v;
+    for (int h = 0; h < 2; ++h) {
+        int off[8];
+        float resv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int r = 8 * h + q, j = (r & 3) + 8 * (r >> 2), co = co0 + (j >> LG);
+            const int rowoff = co < cout ? co * cs : kTrBad;          // one multiply per distinct channel after CSE
+            off[q] = rowoff + t.po[j & ((1 << LG) - 1)];
         }
+        if (resf) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) resv[q] = rcol[max(off[q], 0)];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int r = 8 * h + q;
+            float v = acc[r] + biasr[r];
+            if (gelu) v = gelu_exact(v);
+            if (resf) v += resv[q];
+            if (imgf) {
+                // the only reader is the next layer's k x k conv (gemm_tap.hip): 16-bit, [co / 8][position][8]
+                const int j = (r & 3) + 8 * (r >> 2), co = co0 + (j >> LG);
+                const size_t chan = (size_t)(co >> 3) * d.yh_n * 8 + (co & 7);
+                const int pos8 = (off[q] - co * cs) * 8;
+                if (off[q] >= 0) yimg[chan + pos8] = (unsigned short)(pack_half2(d.half, v, 0.f) & 0xffffu);
+            } else {
+                *(off[q] >= 0 ? ycol + off[q] : sink) = v;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 

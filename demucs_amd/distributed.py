@@ -334,6 +334,9 @@ def apply_model_sharded(model, mix: torch.Tensor, shifts: int = 0, overlap: floa
         total /= torch.tensor(totals, device=device, dtype=torch.float32)[None, :, None, None]
     if ev0 is not None:
         _timing.append((ev0, ev1, ev2, _mark(device)))
+    for sub in models:                 # after the last collective: a rank that raised earlier would leave the others waiting in it
+        if isinstance(sub, HDemucs):
+            sub.check()                # a time-out of the last forward's recurrence would otherwise pass unnoticed
     return total
 
 

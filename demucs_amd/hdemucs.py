@@ -161,6 +161,14 @@ class HDemucs:
         lib = _lib.load()
         return sum(int(lib.mi_hmodel_device_bytes(C.c_void_p(h))) for (dev, _aux), (h, _) in self._handles.items() if dev == self._device)
 
+    def check(self) -> None:
+        """Wait for the current stream and raise if a forward of this model lost its BLSTM recurrence to a time-out (the engine
+        notices by itself only when the NEXT forward starts): `apply_model` calls this before it hands a track's stems on."""
+        lib = _lib.load()
+        for (dev, _aux), (h, _) in self._handles.items():
+            if dev == self._device:
+                _lib.check(lib.mi_hmodel_status(C.c_void_p(h), C.c_void_p(_lib.current_stream_ptr())), "mi_hmodel_status")
+
     def profile_begin(self) -> None:
         """Per-kernel-class HIP-event timing of the MAIN engine handle from here to profile_end (bench.py)."""
         h = self._handles[(self._device, False)][0]

@@ -95,6 +95,13 @@ void mi_hmodel_destroy(void *handle);
 int mi_hmodel_forward(void *handle, const float *mix_dev, float *out_dev, int32_t B, int32_t length, void *stream);
 int mi_hmodel_tap(void *handle, const char *name, float *dst_dev, int32_t B, int64_t *numel_per_item, void *stream);
 int64_t mi_hmodel_device_bytes(void *handle);
+/* mi_hmodel_status: waits for `stream` and reports whether any forward of this handle so far lost its BLSTM recurrence
+ *   (demucs/demucs.py:20-67 runs as one persistent kernel per sequence; a hidden-state wait that exceeds 0.3 s -- only when other
+ *   persistent kernels keep part of its grid from becoming resident, e.g. two processes on one GPU -- abandons the sequence and sets a
+ *   sticky word).  mi_hmodel_forward checks that word when it STARTS, so a time-out in the LAST forward of a job would go unnoticed:
+ *   callers that hand results on (demucs_amd.apply.apply_model does) ask here once the work is enqueued.  MI_OK, or MI_EINVAL with the
+ *   message of mi_last_error. */
+int mi_hmodel_status(void *handle, void *stream);
 
 /* Debug / parity aid: copy an internal activation left behind by the last mi_model_forward
  * (first B items) into dst_dev (may be NULL to query *numel_per_item only).  Names: "x0" (normalised CaC spectrogram),

@@ -52,7 +52,7 @@ def klass(name):
         return f"conv_gemm_{'bf16' if m.group(1) == '1' else 'f16'}<linear,tile128,1x1>"
     # kernels named in north_star's HBM-bound list: STFT (K1), iSTFT (K15), the fused DConv kernels, the scheduler's OLA
     for k in ("attention_heads_kernel", "attention_half_kernel", "attention_kernel", "dconv_rowlds_kernel", "dconv_row_kernel", "dconv_t_conv3_kernel", "dconv_t_gram_kernel", "dconv_t_out_kernel",
-              "istft_fused_kernel", "istft_frames_kernel", "istft_ola_kernel", "lstm_persist_kernel", "stft_frames_kernel", "cac_transpose_kernel", "spec_transpose_kernel", "cac_transpose_strip_kernel", "spec_transpose_strip_kernel",
+              "istft_fused_kernel", "istft_frames_kernel", "istft_ola_kernel", "lstm_persist_kernel", "stft_frames_kernel", "stft_walk_kernel", "cac_transpose_kernel", "spec_transpose_kernel", "cac_transpose_strip_kernel", "spec_transpose_strip_kernel",
               "ola_accumulate_kernel", "ola_finish_kernel", "segments_gather_kernel", "token_tile_kernel", "row_stats_kernel", "gn_gelu_kernel"):
         if k in name:
             return k
