@@ -6,7 +6,9 @@
 // One 256-thread workgroup computes one 4096-point complex FFT entirely in LDS (Stockham
 // autosort, three radix-16 passes, twiddles staged in LDS).  The two audio channels of a frame
 // are packed as real/imaginary parts of ONE complex transform, halving the FFT count.
-// Layouts:   frame-major scratch  zt[b][t][4][2048]   (coalesced frame stores), then a tiled
+// A workgroup walks a run of consecutive frames (forward: stft_walk_kernel; inverse: istft_fused_kernel, which also keeps the
+// overlap-add in registers) with the next frame's data prefetched under the current frame's passes.
+// Layouts:   frame-major scratch  zt[b][t][4][2048]   (coalesced frame stores), then a strip
 // transpose applies the per-item normalisation and writes the conv layout x[b][4][2048][T].
 #include "common.h"
 #include "kernels.h"

@@ -128,10 +128,13 @@ int mi_set_two_streams(int32_t enabled);
  *   (frames to memory, then a gather): same summation order, bit-identical output -- kept for A/B runs and as the check of the
  *   fused kernel.  Process-wide; returns the previous setting.  Initial value: 1 unless MI_ISTFT_SPLIT is set. */
 int mi_set_istft_fused(int32_t enabled);
-/* mi_set_transpose_tiles: the layout changes either side of the transforms (frame-major scratch <-> the conv layout
- *   x[b][c][bin][frame] of demucs/htdemucs.py:420-471) run as STRIP kernels (0, the default: a workgroup moves 32 bins x all frames
- *   of a plane, one contiguous run on the conv-layout side); 1 selects the 32 x 32 tile kernels of rounds 1-3: same values, same
- *   arithmetic, bit-identical output -- kept for A/B runs and as the check of the strip kernels.  Process-wide; returns the previous
+/* mi_set_transpose_tiles: the kernels either side of the transforms (demucs/htdemucs.py:420-471, demucs/spec.py:11-47).  0, the
+ *   default: the STFT walks a run of consecutive frames per workgroup (twiddles and window read once per run, the next frame's samples
+ *   prefetched), and the layout changes between the frame-major scratch and the conv layout x[b][c][bin][frame] move 32 bins x all
+ *   frames of a plane per workgroup (one contiguous run on the conv-layout side).  1 selects the kernels of rounds 1-3 for all three
+ *   (one frame per workgroup, 32 x 32 tile transposes); as a bit mask 2 selects only the tile cac_transpose, 4 only the tile
+ *   spec_transpose.  Same values, same arithmetic, bit-identical spectrograms and waveforms (the float64 normalisation sums are
+ *   accumulated in another order) -- kept for A/B runs and as the check of the default kernels.  Process-wide; returns the previous
  *   setting.  Initial value: 0 unless MI_TRANSPOSE_TILES is set. */
 int mi_set_transpose_tiles(int32_t enabled);
 int mi_profile_begin(void *handle);
