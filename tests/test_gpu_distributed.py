@@ -74,7 +74,11 @@ def _worker(rank, world, port, length, out_path, case):
         from demucs_amd.hdemucs import HDemucs
         from demucs_amd.hdemucs_weights import HDemucsConfig, synthetic_hdemucs_state_dict
         hcfg = HDemucsConfig()
-        hm = HDemucs(hcfg.sources, max_batch=3, compute_dtype="f16" if case == "hdemucs" else "f32")
+        # float32 on purpose: with the ranks of this test sharing ONE GPU, another process's 16-bit matrix-core kernels corrupt this
+        # package's (tools/micro/mfma_neighbour.hip: fp32 MFMA never, 16-bit MFMA with VGPR accumulators always; DESIGN.md S8,
+        # INTEGRATION.md "do not share the GPU") -- the f16 run of this case passed twice and failed once (7.5e-3) on unchanged
+        # code.  The f16 engine goes through the sharded scheduler with one process on the GPU in tests/test_gpu_nccl.py.
+        hm = HDemucs(hcfg.sources, max_batch=3, compute_dtype="f32")
         hm.load_state_dict(synthetic_hdemucs_state_dict(hcfg, 1))
         if case == "hdemucs":                              # one pass of a plain model: bit-identical
             hm.segment = 44
