@@ -56,7 +56,14 @@ int g_two_streams = 1;
 // side stream and the two fork / join events of the two-branch schedule (created on first use)
 int Model::side_streams() {
     if (side_st) return MI_OK;
-    MI_HIP(hipStreamCreateWithFlags(&side_st, hipStreamNonBlocking));
+    // MI_SIDE_PRIO=low / high: the side stream at the device's least / greatest priority (A/B switch; default: normal priority)
+    const char *prio = getenv("MI_SIDE_PRIO");
+    if (prio) {
+        int least = 0, greatest = 0;
+        MI_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        MI_HIP(hipStreamCreateWithPriority(&side_st, hipStreamNonBlocking, prio[0] == 'l' ? least : greatest));
+    } else
+        MI_HIP(hipStreamCreateWithFlags(&side_st, hipStreamNonBlocking));
     MI_HIP(hipEventCreateWithFlags(&ev_main, hipEventDisableTiming));
     MI_HIP(hipEventCreateWithFlags(&ev_side, hipEventDisableTiming));
     return MI_OK;
