@@ -2,8 +2,8 @@
 
 Only what sits on the tensor -> tensor path is provided: construction around an already built
 model (the model zoo download of `demucs/pretrained.py` needs the network and is out of scope),
-`update_parameter`, `separate_tensor` (api.py:241-291) and the `samplerate / audio_channels / model`
-properties.  Audio file loading and the stem writers are not part of this path.
+`update_parameter`, `separate_tensor` (api.py:241-291), the `samplerate / audio_channels / model`
+properties and `list_models` for a local folder (api.py:322-347).  Audio file loading and the stem writers are not part of this path.
 
 `separate_tensor` is a device path: ONE host -> device copy of the raw `wav`, the resampler kernel when `sr`
 differs (`convert_audio`, demucs_amd/audio.py), the mono mean / unbiased std by a device reduction
@@ -16,7 +16,8 @@ reference normalises it in place and restores it, which leaves rounding differen
 from __future__ import annotations
 
 import ctypes as C
-from typing import Callable, Dict, Optional, Tuple
+from pathlib import Path
+from typing import Callable, Dict, Optional, Tuple, Union
 
 import torch
 
@@ -24,7 +25,7 @@ from . import _lib
 from .audio import convert_audio
 from .apply import BagOfModels, _is_engine, _to_host, apply_model
 
-__all__ = ["Separator", "LoadModelError"]
+__all__ = ["Separator", "LoadModelError", "list_models"]
 
 
 class LoadModelError(Exception):
@@ -144,3 +145,17 @@ class Separator:
     @property
     def model(self):
         return self._model
+
+
+def list_models(repo: Optional[Union[str, Path]] = None) -> Dict[str, Dict[str, Union[str, Path]]]:
+    """api.py:322-347: `{"single": {signature: package path}, "bag": {name: yaml path}}` of a local model folder.  Without `repo`
+    the reference lists its remote zoo (`remote/files.txt` + the bag YAMLs it ships); offline only `demucs_unittest`, the one
+    model that needs no download (pretrained.py:27-29), can be named."""
+    if repo is None:
+        return {"single": {"demucs_unittest": "built in (HDemucs(channels=4), pretrained.py:27-29)"}, "bag": {}}
+    from .states import LocalRepo
+    repo = Path(repo)
+    if not repo.is_dir():
+        raise LoadModelError(f"{repo} must exist and be a directory.")
+    local = LocalRepo(repo)
+    return {"single": dict(local._models), "bag": dict(local._bags)}

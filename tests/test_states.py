@@ -110,6 +110,14 @@ def test_local_repo_reads_signatures_checksums_and_bags(tmp_path, fake_reference
         assert isinstance(repo.get_model("f7e0c4bc"), HTDemucs)
     with pytest.raises(states.ModelLoadingError):
         repo.get_model("nope")
+    # demucs/api.py:322-347 list_models: {"single": {signature: path}, "bag": {name: path}}
+    from demucs_amd.api import LoadModelError, list_models
+    listed = list_models(tmp_path)
+    assert sorted(listed["single"]) == sorted(sigs) and list(listed["bag"]) == ["two_ft"]
+    assert listed["single"]["d12395a8"] == tmp_path / "d12395a8.th" and listed["bag"]["two_ft"] == tmp_path / "two_ft.yaml"
+    assert list(list_models()["single"]) == ["demucs_unittest"] and list_models()["bag"] == {}
+    with pytest.raises(LoadModelError):
+        list_models(tmp_path / "missing")
     # a corrupted file no longer matches the checksum in its name
     bad = next(p for p in tmp_path.iterdir() if p.name.startswith("f7e0c4bc-"))
     bad.write_bytes(bad.read_bytes()[:-1] + b"\\0")
