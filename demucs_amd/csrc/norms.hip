@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void token_tile_kernel(const float *__restrict
                                                          const float2 *__restrict__ gstat, float eps, float *__restrict__ y,
                                                          float2 *__restrict__ ostat, uint4 *__restrict__ img, int64_t img_n, int img_dtype) {
     __shared__ float red[4][64][2];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // wave-uniform: w[c], b[c] become scalar loads
     const int t = blockIdx.x * 64 + lane;
     const bool ok = t < T;
     const size_t base = (size_t)blockIdx.y * C * T + (ok ? t : 0);
@@ -149,20 +149,37 @@ __global__ __launch_bounds__(256) void token_tile_kernel(const float *__restrict
         y0 = v;
     }
     float s1 = 0.f, s2 = 0.f;
-    float q8[8];
-    for (int c = c0; c < c0 + cw; ++c) {
+    // eight channels per trip: their loads are issued together (one channel per trip left ONE load in flight per wave: the trip
+    // waited for x, w[c] and b[c] before the next address was formed); same per-element arithmetic and summation order
+    int c = c0;
+    for (; c + 8 <= c0 + cw; c += 8) {
+        float xv[8], pv[8], q8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xv[e] = x[base + (size_t)(c + e) * T];
+        if (MODE == 0 && pe) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pv[e] = pe[(size_t)(c + e) * T + (ok ? t : 0)];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float v = (xv[e] - mean) * rstd * w[c + e] + bvec[c + e];
+            if (MODE == 0 && pe) v += pv[e];
+            if (ok) y[base + (size_t)(c + e) * T] = v;
+            const float dv = v - y0;
+            s1 += dv; s2 += dv * dv;
+            q8[e] = v;
+        }
+        if (img && ok)                                    // cw is a multiple of 8 (checked by the launcher)
+            img[(size_t)(c >> 3) * img_n + (size_t)blockIdx.y * T + t] =
+                make_uint4(pack_half2(img_dtype, q8[0], q8[1]), pack_half2(img_dtype, q8[2], q8[3]), pack_half2(img_dtype, q8[4], q8[5]),
+                           pack_half2(img_dtype, q8[6], q8[7]));
+    }
+    for (; c < c0 + cw; ++c) {                            // widths whose quarter is not a multiple of 8 (never with an image)
         float v = (x[base + (size_t)c * T] - mean) * rstd * w[c] + bvec[c];
         if (MODE == 0 && pe) v += pe[(size_t)c * T + (ok ? t : 0)];
         if (ok) y[base + (size_t)c * T] = v;
         const float dv = v - y0;
         s1 += dv; s2 += dv * dv;
-        if (img) {                                        // cw is a multiple of 8 (checked by the launcher)
-            q8[c & 7] = v;
-            if ((c & 7) == 7 && ok)
-                img[(size_t)(c >> 3) * img_n + (size_t)blockIdx.y * T + t] =
-                    make_uint4(pack_half2(img_dtype, q8[0], q8[1]), pack_half2(img_dtype, q8[2], q8[3]), pack_half2(img_dtype, q8[4], q8[5]),
-                               pack_half2(img_dtype, q8[6], q8[7]));
-        }
     }
     if (!ostat) return;
     red[wv][lane][0] = s1; red[wv][lane][1] = s2;
